@@ -1,0 +1,194 @@
+#!/usr/bin/env python
+"""bench.py -- MIPS queries/s of the EMDR2 evidence search on MI355X (BASELINE.json configs[1]).
+
+One "step" = one `search_mips_index` call: 512 fp16 queries against the 21,015,324 x 768 fp16
+evidence index resident in HBM, top-50, including query packing, the fused scan, candidate
+selection, exact re-scoring and (N > 1) the all-gather + merge.  Inputs are resident in HBM when
+the timed region starts.  With --gpus N the index is row-sharded N ways (one process per GPU, RCCL);
+total work is fixed, so scaling is "strong".
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R] [--queries Q] [--topk k]
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the scan launch over the
+last, largest row segment), timed with hipEvents on the launch stream inside the library;
+`cpu_baseline` times the oracle's CPU port (fp32-accumulate GEMM + top-k, all host cores) on a
+bounded row sample (rank 0, N = 1 only).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+N_ROWS_FULL = 21_015_324          # psgs_w100 passages
+DIM = 768
+HBM_PEAK_GBPS = 8000.0            # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = 2500.0         # dense fp16/bf16 MFMA peak
+GEN_CHUNK = 1 << 19
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--rows", type=int, default=N_ROWS_FULL)
+    ap.add_argument("--queries", type=int, default=512)
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    return ap.parse_args()
+
+
+def synth_rows(lo, hi, seed=1234):
+    """Rows [lo, hi) of the synthetic index: fp16(N(0,1)), generated on the device chunk by chunk from a
+    (seed, chunk) keyed generator so that a row's content does not depend on the sharding."""
+    c0, c1 = lo // GEN_CHUNK, (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    for c in range(c0, c1):
+        g = torch.Generator(device="cuda").manual_seed(seed * 1_000_003 + c)
+        block = torch.randn((GEN_CHUNK, DIM), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
+        yield block[a - c * GEN_CHUNK: b - c * GEN_CHUNK]
+
+
+def cpu_baseline(args, queries_cpu):
+    """Reference arithmetic on the host cores: fp32-accumulate GEMM (torch/MKL), one rounding to fp16,
+    top-k -- oracle.mips_oracle.topk_blas -- on a bounded row sample; reported in the metric's unit by
+    scaling rows/s to the full index (stated in `sample`)."""
+    from oracle import mips_oracle as mo
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    nq = queries_cpu.shape[0]
+    probe_rows = 65536
+    g = torch.Generator().manual_seed(7)
+    rows = torch.randn((probe_rows, DIM), generator=g).to(torch.float16).numpy()
+    mo.topk_blas(rows[:8192], queries_cpu, args.topk)                       # warm-up
+    t0 = time.perf_counter(); mo.topk_blas(rows, queries_cpu, args.topk); t_probe = time.perf_counter() - t0
+    n_s = int(min(max(probe_rows, probe_rows * args.cpu_seconds / max(t_probe, 1e-3)), 4_000_000))
+    n_s = max(probe_rows, n_s // probe_rows * probe_rows)
+    reps = n_s // probe_rows
+    t0 = time.perf_counter()
+    for _ in range(reps):                                                     # same rows re-scanned: only the rate matters
+        mo.topk_blas(rows, queries_cpu, args.topk)
+    t = time.perf_counter() - t0
+    row_queries_per_s = (reps * probe_rows) * nq / t
+    return {"value": row_queries_per_s / args.rows, "unit": "queries/s", "cores": cores, "kind": "port",
+            "sample": "%d queries x %d rows (fp32 GEMM + fp16 round + top-%d, torch CPU, %d threads) in %.1f s; "
+                      "rate scaled to the %d-row index" % (nq, reps * probe_rows, args.topk, cores, t, args.rows)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+
+    from emdr2_amd import _native
+    from emdr2_amd.data.emdr2_index import HipIndexShard, merge_shard_results, shard_bounds
+    lib = _native.lib()
+
+    lo, hi = shard_bounds(args.rows, world)[rank]
+    shard = HipIndexShard(DIM, hi - lo, lo)
+    for block in synth_rows(lo, hi):
+        shard.append_rows(block)
+    gq = torch.Generator(device="cuda").manual_seed(4321)
+    queries = torch.randn((args.queries, DIM), generator=gq, device="cuda", dtype=torch.float32).to(torch.float16)
+    nq, k = args.queries, args.topk
+
+    def step():
+        dist, idx, row, flags = shard.search(queries, k, exact_fallback=False)
+        if world > 1:
+            packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
+            gathered = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+            torch.distributed.all_gather_into_tensor(gathered, packed)
+            dist, idx, row = merge_shard_results(gathered[:, 0].to(torch.int16).view(torch.float16).contiguous(),
+                                                 gathered[:, 1].to(torch.int32).contiguous(), gathered[:, 2].contiguous())
+        return dist, idx, flags
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        out = step()
+    fence()
+    flags_total = int(out[2].abs().sum().item()) if args.warmup else 0
+    lib.emdr2_mips_set_timing(1)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    flags_total += int(out[2].abs().sum().item())
+
+    # per-launch scan timings recorded with hipEvents on the launch stream during the timed region
+    cap = 2048
+    ms = (ctypes.c_float * cap)(); rows_l = (ctypes.c_int64 * cap)(); n_l = ctypes.c_int()
+    _native.check(lib.emdr2_mips_timing_collect(ms, rows_l, cap, ctypes.byref(n_l)), "timing_collect")
+    lib.emdr2_mips_set_timing(0)
+    launches = [(ms[i], rows_l[i]) for i in range(n_l.value)]
+    big = max(r for _, r in launches)
+    dom = [m for m, r in launches if r == big]
+    dom_ms = sum(dom) / len(dom)
+    scan_ms_per_step = sum(m for m, _ in launches) / max(args.steps, 1)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        flops = 2.0 * nq * big * DIM
+        bytes_alg = float(big) * DIM * 2
+        tflops = flops / (dom_ms * 1e-3) / 1e12
+        gbps = bytes_alg / (dom_ms * 1e-3) / 1e9
+        bound = "mfma" if nq > 312 else "hbm"        # machine balance 2.5e15 / 8e12
+        roofline = {"bound": bound,
+                    "achieved": tflops if bound == "mfma" else gbps,
+                    "peak": MFMA_PEAK_TFLOPS if bound == "mfma" else HBM_PEAK_GBPS,
+                    "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
+                    "frac": (tflops / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbps / HBM_PEAK_GBPS),
+                    "traffic": None,
+                    "kernel": "mips_scan_kernel (last row segment: %d rows/launch)" % big,
+                    "kernel_ms": dom_ms, "scan_ms_per_step": scan_ms_per_step,
+                    "hbm_gbps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS,
+                    "mfma_tflops": tflops, "mfma_frac": tflops / MFMA_PEAK_TFLOPS}
+        result = {
+            "metric": "mips_queries_per_sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f16",
+            "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: MIPS-only top-%d, %d queries/search over a %d x %d fp16 index resident in HBM"
+                                   % (k, nq, args.rows, DIM),
+                       "rows": args.rows, "dim": DIM, "queries_per_step": nq, "top_k": k,
+                       "parallelism": "index row-sharded x%d, all-gather(top-k) + merge" % world,
+                       "cus": int(lib.emdr2_device_cu_count()), "unproven_queries": flags_total},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(args, queries.cpu().numpy())
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,71 @@
+"""ctypes binding of libemdr2_hip.so (C ABI: include/emdr2_mips.h).
+
+The library is built in-tree by `__graft_entry__.build()` / `make -C emdr2_amd/csrc`.  If it is
+missing this module raises at first use -- the product path never falls back to a CPU or eager
+implementation.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")
+
+EMDR2_ABI_VERSION = 1
+FLAG_AMBIGUOUS = 1
+FLAG_OVERFLOW = 2
+MAX_TOPK = 120
+
+_ERRORS = {-1: "bad argument", -2: "workspace too small", -3: "HIP launch/runtime error", -4: "unsupported shape"}
+
+# name -> (restype, argtypes); mirrors include/emdr2_mips.h one to one
+_vp, _i32, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_int64, ctypes.c_size_t
+SIGNATURES = {
+    "emdr2_abi_version": (_i32, []),
+    "emdr2_device_cu_count": (_i32, []),
+    "emdr2_mips_layout_bytes": (_i32, [_i64, _i32, ctypes.POINTER(_sz)]),
+    "emdr2_mips_pack_rows": (_i32, [_vp, _i64, _i32, _i64, _i64, _vp, _vp, _vp]),
+    "emdr2_mips_unpack_rows": (_i32, [_vp, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "emdr2_mips_workspace_bytes": (_i32, [_i32, _i32, _i32, ctypes.POINTER(_sz)]),
+    "emdr2_mips_search": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_exact_workspace_bytes": (_i32, [_i64, _i32, ctypes.POINTER(_sz)]),
+    "emdr2_mips_search_exact": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_merge": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "emdr2_mips_debug_scores": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_set_timing": (_i32, [_i32]),
+    "emdr2_mips_timing_collect": (_i32, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i64), _i32, ctypes.POINTER(_i32)]),
+}
+
+_lib = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises NativeError when the library is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NativeError(
+                "libemdr2_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C emdr2_amd/csrc`. There is no CPU fallback for the EMDR2 hot path." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)       # AttributeError here == header/library drift
+            fn.restype, fn.argtypes = res, args
+        if handle.emdr2_abi_version() != EMDR2_ABI_VERSION:
+            raise NativeError("libemdr2_hip.so ABI version mismatch")
+        _lib = handle
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise NativeError("%s failed: %s (%d)" % (what, _ERRORS.get(rc, "unknown error"), rc))
+
+
+def stream_ptr(stream=None):
+    import torch
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return ctypes.c_void_p(s.cuda_stream)

@@ -1,0 +1,290 @@
+// emdr2_amd/csrc/mips_api.hip -- C ABI (include/emdr2_mips.h) over the MIPS kernels.
+#include "../../include/emdr2_mips.h"
+#include "mips_kernels.h"
+#include <stdlib.h>
+
+namespace {
+
+#define TIMING_SLOTS 2048
+struct Timing {
+    bool enabled = false;
+    hipEvent_t ev[2 * TIMING_SLOTS] = {};
+    int created = 0;
+    int n = 0;
+    int64_t rows[TIMING_SLOTS] = {};
+} g_timing;
+
+int cu_count()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return cus;
+}
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+int env_int(const char *name, int dflt)
+{
+    const char *v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
+struct Workspace {
+    char *q_tiled;
+    float *qnorm, *tau;
+    unsigned *count;
+    uint2 *cand;
+};
+
+size_t carve(char *base, int dim, Workspace *w)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    char *a = take((size_t)(dim / 32) * 512 * 64);
+    char *b = take(512 * sizeof(float));
+    char *c = take(512 * sizeof(float));
+    char *d = take(512 * sizeof(unsigned));
+    char *e = take((size_t)512 * CAPQ * sizeof(uint2));
+    if (w) { w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; }
+    return off;
+}
+
+bool bad_shape(int64_t n_rows, int dim) { return n_rows < 0 || n_rows >= ((int64_t)1 << 31) - 1024 || dim < 64 || dim > 8192 || (dim % 32) != 0; }
+
+} // namespace
+
+extern "C" {
+
+int emdr2_abi_version(void) { return EMDR2_ABI_VERSION; }
+
+int emdr2_device_cu_count(void) { return cu_count(); }
+
+int emdr2_mips_set_timing(int enabled)
+{
+    g_timing.enabled = enabled != 0;
+    g_timing.n = 0;
+    return EMDR2_OK;
+}
+
+int emdr2_mips_timing_collect(float *ms, int64_t *rows, int max_n, int *n_out)
+{
+    const int n = g_timing.n < max_n ? g_timing.n : max_n;
+    for (int i = 0; i < n; ++i) {
+        if (hipEventSynchronize(g_timing.ev[2 * i + 1]) != hipSuccess) return EMDR2_E_LAUNCH;
+        if (hipEventElapsedTime(&ms[i], g_timing.ev[2 * i], g_timing.ev[2 * i + 1]) != hipSuccess) return EMDR2_E_LAUNCH;
+        rows[i] = g_timing.rows[i];
+    }
+    if (n_out) *n_out = n;
+    g_timing.n = 0;
+    return EMDR2_OK;
+}
+
+int emdr2_mips_layout_bytes(int64_t n_rows, int dim, size_t *bytes)
+{
+    if (!bytes || bad_shape(n_rows, dim)) return EMDR2_E_BADARG;
+    const int64_t padded = (n_rows + 511) / 512 * 512;
+    *bytes = (size_t)padded * dim * 2;
+    return EMDR2_OK;
+}
+
+int emdr2_mips_pack_rows(const void *rows_rm, int64_t n_chunk, int dim, int64_t row_offset, int64_t n_rows_total,
+                         void *tiled, float *emax_sq, emdr2_stream_t stream)
+{
+    if (!rows_rm || !tiled || !emax_sq || bad_shape(n_rows_total, dim) || n_chunk < 0 || row_offset < 0 ||
+        row_offset + n_chunk > n_rows_total)
+        return EMDR2_E_BADARG;
+    return mips_launch_pack_rows(rows_rm, n_chunk, dim, row_offset, tiled, emax_sq, (hipStream_t)stream);
+}
+
+int emdr2_mips_unpack_rows(const void *tiled, int64_t n_rows_total, int dim, const int64_t *row_ids, int64_t n_out,
+                           void *rows_rm, emdr2_stream_t stream)
+{
+    if (!tiled || !row_ids || !rows_rm || bad_shape(n_rows_total, dim) || n_out < 0) return EMDR2_E_BADARG;
+    return mips_launch_unpack_rows(tiled, dim, row_ids, n_out, rows_rm, (hipStream_t)stream);
+}
+
+int emdr2_mips_workspace_bytes(int n_q, int dim, int k, size_t *bytes)
+{
+    if (!bytes || n_q < 1 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(0, dim)) return EMDR2_E_BADARG;
+    *bytes = carve(nullptr, dim, nullptr);
+    return EMDR2_OK;
+}
+
+static int variant_for(int nq) { return nq <= 128 ? 2 : (nq <= 256 ? 1 : 0); }
+static const int kBM[3] = {128, 256, 512};
+static const int kBN[3] = {512, 256, 128};
+
+int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
+                      const void *queries, int n_q, int k, const int32_t *ids, void *out_dist, int32_t *out_idx,
+                      int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                      emdr2_stream_t stream_)
+{
+    if (!tiled || !emax_sq || !queries || !out_dist || !out_idx || !out_row || !out_flags || !workspace) return EMDR2_E_BADARG;
+    if (n_q < 1 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
+    Workspace w;
+    if (carve((char *)workspace, dim, &w) > workspace_bytes) return EMDR2_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    const int kp = k <= 56 ? 64 : 128;
+    const int seg0 = env_int("EMDR2_MIPS_SEG0", 2048) / 512 * 512;
+    const int growth = env_int("EMDR2_MIPS_GROWTH", 32);
+    if (seg0 < 512 || seg0 > (int)CAPQ - 512 || growth < 2) return EMDR2_E_BADARG;
+    const int force_variant = env_int("EMDR2_MIPS_VARIANT", -1);
+    const int cus = cu_count();
+
+    for (int q0 = 0; q0 < n_q; q0 += EMDR2_MAX_QUERIES_PER_PASS) {
+        const int nqp = (n_q - q0) < EMDR2_MAX_QUERIES_PER_PASS ? (n_q - q0) : EMDR2_MAX_QUERIES_PER_PASS;
+        int variant = variant_for(nqp);
+        if (force_variant >= 0 && force_variant <= 2 && kBN[force_variant] >= nqp) variant = force_variant;
+        const int BM = kBM[variant], BN = kBN[variant];
+        const uint16_t *qp = (const uint16_t *)queries + (size_t)q0 * dim;
+        int rc;
+        if ((rc = mips_launch_pack_queries(qp, nqp, dim, BN, w.q_tiled, w.qnorm, stream))) return rc;
+        const int64_t dense_rows = n_rows < seg0 ? n_rows : seg0;
+        if ((rc = mips_launch_init(w.tau, w.count, out_flags + q0, BN, nqp, (unsigned)dense_rows, stream))) return rc;
+
+        ScanParams sp;
+        sp.e_tiled = (const char *)tiled;
+        sp.q_tiled = w.q_tiled;
+        sp.tau = w.tau;
+        sp.cand = w.cand;
+        sp.count = w.count;
+        sp.flags = out_flags + q0;
+        sp.dense_out = nullptr;
+        sp.nch = dim / 32;
+        sp.n_rows = (int)n_rows;
+        sp.n_q = nqp;
+        sp.capq = CAPQ;
+        sp.dense_row0 = 0;
+
+        int64_t done = 0, seg_end = dense_rows;
+        int64_t next_boundary = (int64_t)seg0 * growth;
+        int mode = 1;
+        while (done < n_rows) {
+            sp.tile_begin = (int)(done / BM);
+            sp.tile_end = (int)((seg_end + BM - 1) / BM);
+            const int tiles = sp.tile_end - sp.tile_begin;
+            const int grid = tiles < cus ? tiles : cus;
+            const bool timed = g_timing.enabled && g_timing.n < TIMING_SLOTS;
+            if (timed) {
+                while (g_timing.created <= g_timing.n) {
+                    if (hipEventCreate(&g_timing.ev[2 * g_timing.created]) != hipSuccess ||
+                        hipEventCreate(&g_timing.ev[2 * g_timing.created + 1]) != hipSuccess)
+                        return EMDR2_E_LAUNCH;
+                    ++g_timing.created;
+                }
+                if (hipEventRecord(g_timing.ev[2 * g_timing.n], stream) != hipSuccess) return EMDR2_E_LAUNCH;
+            }
+            if ((rc = mips_launch_scan(variant, mode, sp, grid, stream))) return rc;
+            if (timed) {
+                if (hipEventRecord(g_timing.ev[2 * g_timing.n + 1], stream) != hipSuccess) return EMDR2_E_LAUNCH;
+                g_timing.rows[g_timing.n] = seg_end - done;
+                ++g_timing.n;
+            }
+            if ((rc = mips_launch_select(w.cand, w.count, w.tau, out_flags + q0, CAPQ, kp, nqp, stream))) return rc;
+            done = seg_end;
+            seg_end = next_boundary < n_rows ? next_boundary : n_rows;
+            if (n_rows - seg_end < seg_end / 4) seg_end = n_rows; // do not leave a sliver for a last launch
+            next_boundary *= growth;
+            mode = 0;
+        }
+
+        FinalizeParams fp;
+        fp.e_tiled = (const char *)tiled;
+        fp.queries = qp;
+        fp.cand = w.cand;
+        fp.count = w.count;
+        fp.tau = w.tau;
+        fp.qnorm = w.qnorm;
+        fp.emax_sq = emax_sq;
+        fp.ids = ids;
+        fp.out_dist = (uint16_t *)out_dist + (size_t)q0 * k;
+        fp.out_idx = out_idx + (size_t)q0 * k;
+        fp.out_row = out_row + (size_t)q0 * k;
+        fp.flags = out_flags + q0;
+        fp.n_rows = n_rows;
+        fp.row_base = row_base;
+        fp.dim = dim;
+        fp.n_q = nqp;
+        fp.k = k;
+        fp.kp = kp;
+        fp.capq = CAPQ;
+        if ((rc = mips_launch_finalize(fp, stream))) return rc;
+    }
+    return EMDR2_OK;
+}
+
+int emdr2_mips_exact_workspace_bytes(int64_t n_rows, int n_sel, size_t *bytes)
+{
+    if (!bytes || n_rows < 1 || n_sel < 0) return EMDR2_E_BADARG;
+    *bytes = align_up((size_t)8 * (size_t)n_rows * sizeof(uint16_t), 256);
+    return EMDR2_OK;
+}
+
+int emdr2_mips_search_exact(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const void *queries,
+                            int n_q, const int32_t *sel, int n_sel, int k, const int32_t *ids, void *out_dist,
+                            int32_t *out_idx, int64_t *out_row, uint32_t *out_flags, void *workspace,
+                            size_t workspace_bytes, emdr2_stream_t stream_)
+{
+    if (!tiled || !queries || !sel || !out_dist || !out_idx || !out_row || !out_flags || !workspace) return EMDR2_E_BADARG;
+    if (n_q < 1 || n_sel < 0 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
+    if (workspace_bytes < (size_t)8 * (size_t)n_rows * sizeof(uint16_t)) return EMDR2_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int b = 0; b < n_sel; b += 8) {
+        const int nb = (n_sel - b) < 8 ? (n_sel - b) : 8;
+        int rc;
+        if ((rc = mips_launch_exact_scores((const char *)tiled, n_rows, dim, (const uint16_t *)queries, sel + b, nb,
+                                           (uint16_t *)workspace, stream)))
+            return rc;
+        if ((rc = mips_launch_exact_select((const uint16_t *)workspace, n_rows, row_base, sel + b, nb, k, ids,
+                                           (uint16_t *)out_dist, out_idx, out_row, out_flags, stream)))
+            return rc;
+    }
+    return EMDR2_OK;
+}
+
+int emdr2_mips_merge(const void *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
+                     void *out_dist, int32_t *out_idx, int64_t *out_row, emdr2_stream_t stream)
+{
+    if (!dist_in || !idx_in || !row_in || !out_dist || !out_idx || !out_row || n_shards < 1 || n_q < 1 || k < 1) return EMDR2_E_BADARG;
+    return mips_launch_merge((const uint16_t *)dist_in, idx_in, row_in, n_shards, n_q, k, (uint16_t *)out_dist, out_idx,
+                             out_row, (hipStream_t)stream);
+}
+
+int emdr2_mips_debug_scores(const void *tiled, int64_t n_rows, int dim, const void *queries, int n_q,
+                            float *out_scores, void *workspace, size_t workspace_bytes, emdr2_stream_t stream_)
+{
+    if (!tiled || !queries || !out_scores || !workspace || n_q < 1 || n_q > 512 || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
+    Workspace w;
+    if (carve((char *)workspace, dim, &w) > workspace_bytes) return EMDR2_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    int variant = variant_for(n_q);
+    const int force_variant = env_int("EMDR2_MIPS_VARIANT", -1);
+    if (force_variant >= 0 && force_variant <= 2 && kBN[force_variant] >= n_q) variant = force_variant;
+    const int BM = kBM[variant], BN = kBN[variant];
+    int rc;
+    if ((rc = mips_launch_pack_queries(queries, n_q, dim, BN, w.q_tiled, w.qnorm, stream))) return rc;
+    ScanParams sp;
+    sp.e_tiled = (const char *)tiled;
+    sp.q_tiled = w.q_tiled;
+    sp.tau = w.tau;
+    sp.cand = w.cand;
+    sp.count = w.count;
+    sp.flags = nullptr;
+    sp.dense_out = out_scores;
+    sp.nch = dim / 32;
+    sp.n_rows = (int)n_rows;
+    sp.n_q = n_q;
+    sp.capq = CAPQ;
+    sp.dense_row0 = 0;
+    sp.tile_begin = 0;
+    sp.tile_end = (int)((n_rows + BM - 1) / BM);
+    const int cus = cu_count();
+    return mips_launch_scan(variant, 2, sp, sp.tile_end < cus ? sp.tile_end : cus, stream);
+}
+
+} // extern "C"

@@ -1,0 +1,494 @@
+// emdr2_amd/csrc/mips_aux.hip -- everything around the scan: HBM re-layout, query packing,
+// candidate selection, exact integer re-scoring + validity proof, shard merge, all-exact fallback.
+#include "mips_device.h"
+#include "mips_kernels.h"
+
+#define CHECK_LAUNCH() (hipGetLastError() == hipSuccess ? 0 : -3)
+
+// ------------------------------------------------------------------------------------------------
+// index re-layout (reference: add_embed_data uploads a dense row-major fp16 matrix,
+// megatron/data/emdr2_index.py:248-256; here the upload is re-tiled into scan order)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_rows_kernel(const uint4 *__restrict__ rows_rm, int64_t n_chunk, int nseg, int64_t row_offset,
+                                 char *__restrict__ tiled)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_chunk * nseg) return;
+    const int64_t r = i / nseg;
+    const int seg = (int)(i - r * nseg);
+    *(uint4 *)(tiled + tiled_seg_offset(row_offset + r, seg, nseg >> 2)) = rows_rm[i];
+}
+
+__global__ void row_norm_max_kernel(const uint4 *__restrict__ rows_rm, int64_t n_chunk, int nseg, float *emax_sq)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    float best = 0.f;
+    for (int64_t r = wave; r < n_chunk; r += nwaves) {
+        float s = 0.f;
+        for (int seg = lane; seg < nseg; seg += 64) {
+            const uint4 v = rows_rm[r * nseg + seg];
+            const half8 h = __builtin_bit_cast(half8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float x = (float)h[j]; s += x * x; }
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        best = fmaxf(best, s);
+    }
+    if (lane == 0 && best > 0.f) atomicMax((unsigned *)emax_sq, __float_as_uint(best)); // non-negative floats order as uints
+}
+
+int mips_launch_pack_rows(const void *rows_rm, int64_t n_chunk, int dim, int64_t row_offset, void *tiled,
+                          float *emax_sq, hipStream_t stream)
+{
+    const int nseg = dim / 8;
+    const int64_t total = n_chunk * nseg;
+    if (total == 0) return 0;
+    const int64_t blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, (const uint4 *)rows_rm, n_chunk, nseg,
+                       row_offset, (char *)tiled);
+    int nb = (int)((n_chunk + 3) / 4);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(row_norm_max_kernel, dim3(nb), dim3(256), 0, stream, (const uint4 *)rows_rm, n_chunk, nseg, emax_sq);
+    return CHECK_LAUNCH();
+}
+
+__global__ void unpack_rows_kernel(const char *__restrict__ tiled, int nseg, const int64_t *__restrict__ row_ids,
+                                   int64_t n_out, uint4 *__restrict__ rows_rm)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_out * nseg) return;
+    const int64_t r = i / nseg;
+    const int seg = (int)(i - r * nseg);
+    rows_rm[i] = *(const uint4 *)(tiled + tiled_seg_offset(row_ids[r], seg, nseg >> 2));
+}
+
+int mips_launch_unpack_rows(const void *tiled, int dim, const int64_t *row_ids, int64_t n_out, void *rows_rm,
+                            hipStream_t stream)
+{
+    const int nseg = dim / 8;
+    const int64_t total = n_out * nseg;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, (const char *)tiled, nseg,
+                       row_ids, n_out, (uint4 *)rows_rm);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// query packing: [n_q, dim] row-major -> per chunk a [bn rows x 64 B] swizzled block (zero padded)
+// ------------------------------------------------------------------------------------------------
+__global__ void pack_queries_kernel(const uint4 *__restrict__ queries, int n_q, int nseg, int bn, char *__restrict__ q_tiled,
+                                    float *__restrict__ qnorm)
+{
+    const int q = blockIdx.x; // one wave per padded query row
+    const int lane = threadIdx.x;
+    float s = 0.f;
+    for (int seg = lane; seg < nseg; seg += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < n_q) {
+            v = queries[(size_t)q * nseg + seg];
+            const half8 h = __builtin_bit_cast(half8, v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float x = (float)h[j]; s += x * x; }
+        }
+        const int c = seg >> 2, sp = (seg & 3) ^ ((q >> 2) & 3);
+        *(uint4 *)(q_tiled + ((size_t)c * bn * 4 + (size_t)q * 4 + sp) * 16) = v;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0 && q < n_q) qnorm[q] = sqrtf(s) * 1.001f;
+}
+
+int mips_launch_pack_queries(const void *queries, int n_q, int dim, int bn, void *q_tiled, float *qnorm,
+                             hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_queries_kernel, dim3(bn), dim3(64), 0, stream, (const uint4 *)queries, n_q, dim / 8, bn, (char *)q_tiled,
+                       qnorm);
+    return CHECK_LAUNCH();
+}
+
+__global__ void init_kernel(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < bn) {
+        tau[i] = -__builtin_inff();
+        count[i] = (i < n_q) ? dense_count : 0u;
+    }
+    if (i < n_q) flags[i] = 0u;
+}
+
+int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count,
+                     hipStream_t stream)
+{
+    hipLaunchKernelGGL(init_kernel, dim3((bn + 255) / 256), dim3(256), 0, stream, tau, count, flags, bn, n_q, dense_count);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// candidate selection: keep the kp largest keys (fp32 score desc, row asc) of each query
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint64_t cand_key(uint2 e)
+{
+    return ((uint64_t)f32_order(__uint_as_float(e.x)) << 32) | (uint64_t)(0xffffffffu - e.y);
+}
+
+// wave 0: find the digit whose descending cumulative count first reaches `need`
+__device__ __forceinline__ void pick_digit(const unsigned *hist, unsigned need, unsigned *out_digit, unsigned *out_need)
+{
+    const int lane = threadIdx.x;
+    unsigned h[4], s = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { h[j] = hist[255 - (4 * lane + j)]; s += h[j]; }
+    unsigned incl = s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const unsigned t = __shfl_up(incl, o);
+        if (lane >= o) incl += t;
+    }
+    unsigned c = incl - s;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (c < need && need <= c + h[j]) { *out_digit = 255 - (4 * lane + j); *out_need = need - c; }
+        c += h[j];
+    }
+}
+
+__global__ void __launch_bounds__(256) select_kernel(uint2 *cand_all, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_digit, sh_need, sh_out;
+    __shared__ uint2 keep[128];
+    const int q = blockIdx.x, tid = threadIdx.x;
+    uint2 *cand = cand_all + (size_t)q * capq;
+    unsigned n = count[q];
+    if (n > capq) { if (tid == 0) { atomicOr(&flags[q], 2u); count[q] = capq; } n = capq; }
+    if (n <= (unsigned)kp) return;
+
+    uint64_t prefix = 0, mask = 0;
+    unsigned need = (unsigned)kp;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        hist[tid] = 0;
+        __syncthreads();
+        for (unsigned i = tid; i < n; i += 256) {
+            const uint64_t k = cand_key(cand[i]);
+            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) pick_digit(hist, need, &sh_digit, &sh_need);
+        __syncthreads();
+        prefix |= (uint64_t)sh_digit << shift;
+        mask |= (uint64_t)0xff << shift;
+        need = sh_need;
+        __syncthreads();
+    }
+    // prefix is now the kp-th largest key; keys are unique, so exactly kp keys are >= prefix
+    if (tid == 0) sh_out = 0;
+    __syncthreads();
+    for (unsigned i = tid; i < n; i += 256) {
+        const uint2 e = cand[i];
+        if (cand_key(e) >= prefix) {
+            const unsigned s = atomicAdd(&sh_out, 1u);
+            if (s < 128) keep[s] = e;
+        }
+    }
+    __syncthreads();
+    if (tid < kp) cand[tid] = keep[tid];
+    if (tid == 0) {
+        count[q] = (unsigned)kp;
+        tau[q] = f32_unorder((uint32_t)(prefix >> 32));
+    }
+}
+
+int mips_launch_select(uint2 *cand, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
+                       hipStream_t stream)
+{
+    hipLaunchKernelGGL(select_kernel, dim3(n_q), dim3(256), 0, stream, cand, count, tau, flags, capq, kp);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// finalize: exact integer re-scoring of <= kp candidates, canonical (fp16 score desc, row asc)
+// order, proof that no pruned row can enter the top-k, output
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint16_t exact_score_wave(const char *e_tiled, int64_t row, const uint16_t *qrow, int nseg, int lane)
+{
+    int64_t lo = 0, hi = 0;
+    for (int seg = lane; seg < nseg; seg += 64) {
+        const uint4 ev = *(const uint4 *)(e_tiled + tiled_seg_offset(row, seg, nseg >> 2));
+        const uint4 qv = *(const uint4 *)(qrow + seg * 8);
+        const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w}, qw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            exact_mac(lo, hi, half_fix((uint16_t)(ew[j] & 0xffff)), half_fix((uint16_t)(qw[j] & 0xffff)));
+            exact_mac(lo, hi, half_fix((uint16_t)(ew[j] >> 16)), half_fix((uint16_t)(qw[j] >> 16)));
+        }
+    }
+    lo = wave_sum_i64(lo);
+    hi = wave_sum_i64(hi);
+    return fixed_to_half(lo, hi);
+}
+
+__global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
+{
+    __shared__ uint64_t fkey[128];
+    __shared__ uint32_t sh_kth;
+    const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint2 *cand = p.cand + (size_t)q * p.capq;
+    unsigned cnt = p.count[q];
+    if (cnt > (unsigned)p.kp) cnt = p.kp;
+    const int nseg = p.dim / 8;
+    const uint16_t *qrow = p.queries + (size_t)q * p.dim;
+
+    for (unsigned j = wave; j < cnt; j += 4) {
+        const unsigned row = cand[j].y;
+        const uint16_t h = exact_score_wave(p.e_tiled, (int64_t)row, qrow, nseg, lane);
+        if (lane == 0) fkey[j] = ((uint64_t)h16_order(h) << 32) | (uint64_t)(0xffffffffu - row);
+    }
+    if (tid == 0) sh_kth = 0;
+    __syncthreads();
+
+    const unsigned kk = cnt < (unsigned)p.k ? cnt : (unsigned)p.k;
+    if ((unsigned)tid < cnt) {
+        const uint64_t mine = fkey[tid];
+        unsigned rank = 0;
+        for (unsigned i = 0; i < cnt; ++i) rank += (fkey[i] > mine);
+        if (rank < kk) {
+            const uint32_t row = 0xffffffffu - (uint32_t)mine;
+            const size_t o = (size_t)q * p.k + rank;
+            p.out_dist[o] = h16_unorder((uint32_t)(mine >> 32));
+            p.out_row[o] = p.row_base + (int64_t)row;
+            p.out_idx[o] = p.ids ? p.ids[row] : (int32_t)(p.row_base + (int64_t)row);
+            if (rank == kk - 1) sh_kth = (uint32_t)(mine >> 32);
+        }
+    }
+    for (unsigned j = kk + tid; j < (unsigned)p.k; j += 256) { // shard holds fewer than k rows
+        const size_t o = (size_t)q * p.k + j;
+        p.out_dist[o] = 0xfc00; p.out_row[o] = -1; p.out_idx[o] = -1;
+    }
+    __syncthreads();
+    if (tid == 0 && p.n_rows > (int64_t)cnt) {
+        // rows outside the candidate list have MFMA score S~ <= tau (the kp-th best S~), hence exact
+        // score <= tau + eps with eps >= |S~ - exact| for a dim-term fp32 accumulation;
+        // if even that bound rounds below the k-th canonical score the top-k is proven.
+        bool ok = (cnt == (unsigned)p.kp) && (kk == (unsigned)p.k);
+        if (ok) {
+            const float eps = (float)p.dim * 2.3841858e-07f /* 2^-22 */ * p.qnorm[q] * (sqrtf(*p.emax_sq) * 1.001f);
+            const float bound = p.tau[q] + eps * 1.0001f;
+            ok = h16_order(f32_to_h16_roundup(bound)) < sh_kth;
+        }
+        if (!ok) atomicOr(&p.flags[q], 1u);
+    }
+}
+
+int mips_launch_finalize(const FinalizeParams &p, hipStream_t stream)
+{
+    hipLaunchKernelGGL(finalize_kernel, dim3(p.n_q), dim3(256), 0, stream, p);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// shard merge: [S, n_q, k] per-shard canonical lists -> [n_q, k], (score desc, global row asc)
+// ------------------------------------------------------------------------------------------------
+#define MERGE_MAX 4096
+__global__ void __launch_bounds__(256) merge_kernel(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards,
+                                                    int n_q, int k, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row)
+{
+    __shared__ uint64_t key[MERGE_MAX];
+    __shared__ unsigned nvalid;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = n_shards * k;
+    if (tid == 0) nvalid = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int s = i / k, j = i - s * k;
+        const size_t src = ((size_t)s * n_q + q) * k + j;
+        const int64_t row = row_in[src];
+        uint64_t kv = 0;
+        if (row >= 0) {
+            kv = ((uint64_t)h16_order(dist_in[src]) << 48) | (0xffffffffffffull - (uint64_t)row);
+            atomicAdd(&nvalid, 1u);
+        }
+        key[i] = kv;
+    }
+    __syncthreads();
+    const unsigned nv = nvalid;
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t mine = key[i];
+        if (mine == 0) continue;
+        unsigned rank = 0;
+        for (int t = 0; t < n; ++t) rank += (key[t] > mine);
+        if (rank < (unsigned)k) {
+            const int s = i / k, j = i - s * k;
+            const size_t src = ((size_t)s * n_q + q) * k + j, o = (size_t)q * k + rank;
+            out_dist[o] = dist_in[src]; out_idx[o] = idx_in[src]; out_row[o] = row_in[src];
+        }
+    }
+    for (unsigned j = nv + tid; j < (unsigned)k; j += 256) {
+        const size_t o = (size_t)q * k + j;
+        out_dist[o] = 0xfc00; out_idx[o] = -1; out_row[o] = -1;
+    }
+}
+
+int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,
+                      int k, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream)
+{
+    if (n_shards * k > MERGE_MAX) return -4;
+    hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(256), 0, stream, dist_in, idx_in, row_in, n_shards, n_q, k, out_dist, out_idx,
+                       out_row);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// all-exact fallback: canonical fp16 keys for EVERY row in integer arithmetic, then a two-level
+// radix threshold + ordered collection (first rows win ties).  Up to 8 queries per index pass.
+// ------------------------------------------------------------------------------------------------
+#define XQ 8
+__global__ void __launch_bounds__(256) exact_scores_kernel(const char *__restrict__ e_tiled, int64_t n_rows, int dim,
+                                                           const uint16_t *__restrict__ queries, const int32_t *__restrict__ sel,
+                                                           int n_sel, uint16_t *__restrict__ hkeys)
+{
+    extern __shared__ int qfix[]; // [n_sel][dim] packed (mant << 8) | shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n_sel * dim; i += 256) {
+        const int f = i / dim, d = i - f * dim;
+        const HalfFix hf = half_fix(queries[(size_t)sel[f] * dim + d]);
+        qfix[i] = (hf.mant << 8) | hf.shift;
+    }
+    __syncthreads();
+    const int nseg = dim / 8;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_rows; row += (int64_t)gridDim.x * 4) {
+        int64_t lo[XQ], hi[XQ];
+#pragma unroll
+        for (int f = 0; f < XQ; ++f) { lo[f] = 0; hi[f] = 0; }
+        for (int seg = lane; seg < nseg; seg += 64) {
+            const uint4 ev = *(const uint4 *)(e_tiled + tiled_seg_offset(row, seg, nseg >> 2));
+            const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w};
+            HalfFix ef[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ef[2 * j] = half_fix((uint16_t)(ew[j] & 0xffff)); ef[2 * j + 1] = half_fix((uint16_t)(ew[j] >> 16)); }
+#pragma unroll
+            for (int f = 0; f < XQ; ++f) {
+                if (f < n_sel) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pq = qfix[f * dim + seg * 8 + j];
+                        HalfFix qf; qf.mant = pq >> 8; qf.shift = pq & 0xff;
+                        exact_mac(lo[f], hi[f], ef[j], qf);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < XQ; ++f) {
+            if (f < n_sel) {
+                const int64_t l = wave_sum_i64(lo[f]), h = wave_sum_i64(hi[f]);
+                if (lane == 0) hkeys[(size_t)f * n_rows + row] = (uint16_t)h16_order(fixed_to_half(l, h));
+            }
+        }
+    }
+}
+
+int mips_launch_exact_scores(const char *e_tiled, int64_t n_rows, int dim, const uint16_t *queries, const int32_t *sel,
+                             int n_sel, uint16_t *hkeys, hipStream_t stream)
+{
+    if (n_sel > XQ) return -1;
+    int64_t nb = (n_rows + 3) / 4;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(exact_scores_kernel, dim3((unsigned)nb), dim3(256), (size_t)n_sel * dim * sizeof(int), stream, e_tiled, n_rows, dim,
+                       queries, sel, n_sel, hkeys);
+    return CHECK_LAUNCH();
+}
+
+#define XS_THREADS 1024
+#define XS_R 8
+__global__ void __launch_bounds__(XS_THREADS) exact_select_kernel(const uint16_t *__restrict__ hkeys, int64_t n_rows, int64_t row_base,
+                                                                  const int32_t *__restrict__ sel, int k, const int32_t *__restrict__ ids,
+                                                                  uint16_t *out_dist, int32_t *out_idx, int64_t *out_row, unsigned *flags)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_digit, sh_need, sh_above, sh_wsum[XS_THREADS / 64];
+    __shared__ uint64_t okey[128];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint16_t *hk = hkeys + (size_t)f * n_rows;
+    const unsigned keff = (int64_t)k < n_rows ? (unsigned)k : (unsigned)n_rows;
+
+    // level 1: high byte
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_rows; i += XS_THREADS) atomicAdd(&hist[hk[i] >> 8], 1u);
+    __syncthreads();
+    if (tid < 64) pick_digit(hist, keff, &sh_digit, &sh_need);
+    __syncthreads();
+    const unsigned bhi = sh_digit, need1 = sh_need;
+    __syncthreads();
+    // level 2: low byte inside the boundary high-byte bucket
+    if (tid < 256) hist[tid] = 0;
+    __syncthreads();
+    for (int64_t i = tid; i < n_rows; i += XS_THREADS) { const unsigned v = hk[i]; if ((v >> 8) == bhi) atomicAdd(&hist[v & 255u], 1u); }
+    __syncthreads();
+    if (tid < 64) pick_digit(hist, need1, &sh_digit, &sh_need);
+    __syncthreads();
+    const unsigned T = (bhi << 8) | sh_digit;   // k-th canonical key
+    const unsigned need_eq = sh_need;           // how many rows with key == T belong to the top-k
+    const unsigned n_above = keff - need_eq;
+    if (tid == 0) sh_above = 0;
+    __syncthreads();
+
+    // collection in row order: all keys > T, and the first need_eq rows with key == T
+    unsigned eq_done = 0;
+    for (int64_t base = 0; base < n_rows; base += (int64_t)XS_THREADS * XS_R) {
+        const int64_t r0 = base + (int64_t)tid * XS_R;
+        unsigned eqm = 0, mycnt = 0;
+        uint16_t v[XS_R];
+#pragma unroll
+        for (int j = 0; j < XS_R; ++j) {
+            const int64_t r = r0 + j;
+            v[j] = r < n_rows ? hk[r] : 0;
+            if (r < n_rows && v[j] > T) { const unsigned s = atomicAdd(&sh_above, 1u); okey[s] = ((uint64_t)v[j] << 32) | (uint64_t)(0xffffffffu - (uint32_t)r); }
+            if (r < n_rows && v[j] == T) { eqm |= 1u << j; ++mycnt; }
+        }
+        // block exclusive scan of mycnt in thread (= row) order
+        unsigned incl = mycnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) sh_wsum[wave] = incl;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+        for (int w = 0; w < XS_THREADS / 64; ++w) { const unsigned s = sh_wsum[w]; if (w < wave) woff += s; total += s; }
+        unsigned rank = eq_done + woff + incl - mycnt;
+#pragma unroll
+        for (int j = 0; j < XS_R; ++j)
+            if (eqm & (1u << j)) { if (rank < need_eq) okey[n_above + rank] = ((uint64_t)T << 32) | (uint64_t)(0xffffffffu - (uint32_t)(r0 + j)); ++rank; }
+        eq_done += total;
+        __syncthreads();
+    }
+    __syncthreads();
+    const int qi = sel[f];
+    if ((unsigned)tid < keff) {
+        const uint64_t mine = okey[tid];
+        unsigned rank = 0;
+        for (unsigned i = 0; i < keff; ++i) rank += (okey[i] > mine);
+        const uint32_t row = 0xffffffffu - (uint32_t)mine;
+        const size_t o = (size_t)qi * k + rank;
+        out_dist[o] = h16_unorder((uint32_t)(mine >> 32));
+        out_row[o] = row_base + (int64_t)row;
+        out_idx[o] = ids ? ids[row] : (int32_t)(row_base + (int64_t)row);
+    }
+    for (unsigned j = keff + tid; j < (unsigned)k; j += XS_THREADS) {
+        const size_t o = (size_t)qi * k + j;
+        out_dist[o] = 0xfc00; out_row[o] = -1; out_idx[o] = -1;
+    }
+    if (tid == 0) flags[qi] = 0;
+}
+
+int mips_launch_exact_select(const uint16_t *hkeys, int64_t n_rows, int64_t row_base, const int32_t *sel, int n_sel,
+                             int k, const int32_t *ids, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row,
+                             unsigned *flags, hipStream_t stream)
+{
+    hipLaunchKernelGGL(exact_select_kernel, dim3(n_sel), dim3(XS_THREADS), 0, stream, hkeys, n_rows, row_base, sel, k, ids, out_dist,
+                       out_idx, out_row, flags);
+    return CHECK_LAUNCH();
+}

@@ -1,0 +1,67 @@
+// emdr2_amd/csrc/mips_kernels.h -- host-visible launch wrappers of the MIPS kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define CAPQ 16384u /* candidate slots per query (8 B each) */
+
+struct ScanParams {
+    const char *e_tiled;  // stripe-tiled index image
+    const char *q_tiled;  // chunk-tiled queries: [nch][BN*64 B]
+    const float *tau;     // [BN] pass iff score >= tau
+    uint2 *cand;          // [BN][capq] (fp32 score bits, local row)
+    unsigned *count;      // [BN]
+    unsigned *flags;      // [n_q]
+    float *dense_out;     // MODE 2
+    int nch;              // dim / 32
+    int tile_begin, tile_end; // workgroup tiles (BM rows each)
+    int n_rows;           // valid rows of the shard
+    int n_q;
+    unsigned capq;
+    int dense_row0;       // MODE 1: first row of the dense segment
+};
+
+// variant: 0 = 128 rows x 512 queries, 1 = 256 x 256, 2 = 512 x 128 ; mode: see mips_scan.hip
+int mips_launch_scan(int variant, int mode, const ScanParams &p, int grid, hipStream_t stream);
+
+int mips_launch_pack_rows(const void *rows_rm, int64_t n_chunk, int dim, int64_t row_offset, void *tiled,
+                          float *emax_sq, hipStream_t stream);
+int mips_launch_unpack_rows(const void *tiled, int dim, const int64_t *row_ids, int64_t n_out, void *rows_rm,
+                            hipStream_t stream);
+// queries row-major fp16 [n_q, dim] -> chunk-tiled image for BN rows (zero padded) + ||q||_2 upper bounds
+int mips_launch_pack_queries(const void *queries, int n_q, int dim, int bn, void *q_tiled, float *qnorm,
+                             hipStream_t stream);
+int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count,
+                     hipStream_t stream);
+// keep the kp best candidates of every query (by (score desc,row asc)), publish tau = kp-th score
+int mips_launch_select(uint2 *cand, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
+                       hipStream_t stream);
+// exact re-scoring of the surviving candidates, canonical order, validity proof, outputs
+struct FinalizeParams {
+    const char *e_tiled;
+    const uint16_t *queries; // row-major [n_q, dim]
+    const uint2 *cand;
+    const unsigned *count;
+    const float *tau;
+    const float *qnorm;
+    const float *emax_sq;
+    const int32_t *ids;
+    uint16_t *out_dist;
+    int32_t *out_idx;
+    int64_t *out_row;
+    unsigned *flags;
+    int64_t n_rows, row_base;
+    int dim, n_q, k, kp;
+    unsigned capq;
+};
+int mips_launch_finalize(const FinalizeParams &p, hipStream_t stream);
+int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,
+                      int k, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
+
+// all-exact fallback
+int mips_launch_exact_scores(const char *e_tiled, int64_t n_rows, int dim, const uint16_t *queries,
+                             const int32_t *sel, int n_sel, uint16_t *hkeys /* [n_sel][n_rows] ordered keys */,
+                             hipStream_t stream);
+int mips_launch_exact_select(const uint16_t *hkeys, int64_t n_rows, int64_t row_base, const int32_t *sel, int n_sel,
+                             int k, const int32_t *ids, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row,
+                             unsigned *flags, hipStream_t stream);

@@ -1,0 +1,331 @@
+"""Evidence-embedding store and MIPS index -- MI355X-native counterpart of the reference's
+megatron/data/emdr2_index.py (same class and method names, same argument meaning):
+
+  OpenRetreivalDataStore        reference emdr2_index.py:16-100   (pickle {'embed_data': {id: fp16[D]}},
+                                                                    per-rank shards, merge)
+  DistributedBruteForceIndex    reference emdr2_index.py:200-305  (fp16 Q*E^T + topk over all GPUs of
+                                                                    ONE process)
+
+What changes underneath: one process per GPU; every rank keeps one contiguous row shard
+of the index resident in HBM in a stripe-tiled layout; `search_mips_index` runs the fused HIP scan
+(libemdr2_hip.so, include/emdr2_mips.h) over the local shard for ALL queries, then ONE all-gather of
+the per-shard (score, row, id) top-k over RCCL and a deterministic k-way merge on every rank.  The
+dense [Q, N] score matrix of the reference is never formed.  Results follow the canonical numerics
+of DESIGN.md section 3: score = RNE_fp16(exact dot), order (score desc, row asc).
+
+There is no CPU path here: without the HIP library / a GPU the index raises.
+"""
+import os
+import pickle
+import shutil
+
+import numpy as np
+import torch
+
+from emdr2_amd import _native
+
+_UPLOAD_ROWS = 1 << 20  # rows per host->device staging chunk (1.5 GiB at D=768)
+
+
+def detach(tensor):
+    return tensor.detach().cpu().numpy()
+
+
+class OpenRetreivalDataStore(object):
+    """Serializable {doc_id -> fp16[D]} store (reference: emdr2_index.py:16-100; the class name keeps
+    the reference's spelling).  File format is the reference's pickle so `--embedding-path`
+    artefacts interoperate."""
+
+    def __init__(self, embedding_path=None, load_from_path=True, rank=None):
+        self.embed_data = dict()
+        if embedding_path is None:
+            from emdr2_amd.global_vars import get_args
+            args = get_args()
+            embedding_path = args.embedding_path
+            rank = args.rank
+        self.embedding_path = embedding_path
+        self.rank = rank
+
+        if load_from_path:
+            self.load_from_file()
+
+        block_data_name = os.path.splitext(self.embedding_path)[0]
+        self.temp_dir_name = block_data_name + '_tmp'
+
+    def state(self):
+        return {'embed_data': self.embed_data}
+
+    def clear(self):
+        self.embed_data = dict()
+
+    def load_from_file(self):
+        with open(self.embedding_path, 'rb') as f:
+            state_dict = pickle.load(f)
+        self.embed_data = state_dict['embed_data']
+
+    def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
+        for idx, embed in zip(row_id, block_embeds):
+            if not allow_overwrite and idx in self.embed_data:
+                raise ValueError("Unexpectedly tried to overwrite block data")
+            self.embed_data[idx] = np.float16(embed)
+
+    def save_shard(self):
+        if not os.path.isdir(self.temp_dir_name):
+            os.makedirs(self.temp_dir_name, exist_ok=True)
+        with open('{}/{}.pkl'.format(self.temp_dir_name, self.rank), 'wb') as writer:
+            pickle.dump(self.state(), writer)
+
+    def merge_shards_and_save(self):
+        shard_names = os.listdir(self.temp_dir_name)
+        seen_own_shard = False
+        for fname in os.listdir(self.temp_dir_name):
+            shard_rank = int(os.path.splitext(fname)[0])
+            if shard_rank == self.rank:
+                seen_own_shard = True
+                continue
+            with open('{}/{}'.format(self.temp_dir_name, fname), 'rb') as f:
+                data = pickle.load(f)
+                old_size = len(self.embed_data)
+                shard_size = len(data['embed_data'])
+                self.embed_data.update(data['embed_data'])
+                assert len(self.embed_data) == old_size + shard_size
+        assert seen_own_shard
+        with open(self.embedding_path, 'wb') as final_file:
+            pickle.dump(self.state(), final_file)
+        shutil.rmtree(self.temp_dir_name, ignore_errors=True)
+        print("Finished merging {} shards for a total of {} embeds".format(
+            len(shard_names), len(self.embed_data)), flush=True)
+
+    # ---- flat views (not in the reference): avoid 21M tiny arrays on the way to the GPU -----------
+    def to_arrays(self):
+        """(ids int32 [N], rows fp16 [N, D]) in dict insertion order == the reference's matrix row order
+        (emdr2_index.py:245)."""
+        n = len(self.embed_data)
+        ids = np.fromiter(self.embed_data.keys(), dtype=np.int64, count=n)
+        if n and (ids.min() < -2 ** 31 or ids.max() >= 2 ** 31):
+            raise ValueError("doc ids must fit int32 (reference returns int32 ids, emdr2_index.py:298)")
+        rows = np.empty((n, len(next(iter(self.embed_data.values()))) if n else 0), dtype=np.float16)
+        for i, v in enumerate(self.embed_data.values()):
+            rows[i] = v
+        return ids.astype(np.int32), rows
+
+
+def shard_bounds(num_rows, world_size):
+    """Row range per rank, torch.chunk semantics like the reference's per-device split
+    (emdr2_index.py:252-254): equal chunks of ceil(N/W) rows, the last one shorter (possibly empty)."""
+    chunk = (num_rows + world_size - 1) // world_size if num_rows else 0
+    return [(min(r * chunk, num_rows), min((r + 1) * chunk, num_rows)) for r in range(world_size)]
+
+
+class HipIndexShard(object):
+    """One contiguous row shard resident in this process's GPU, stripe-tiled for the HIP scan."""
+
+    def __init__(self, dim, n_rows, row_base, device=None):
+        self.lib = _native.lib()
+        if not torch.cuda.is_available():
+            raise _native.NativeError("HipIndexShard needs a GPU; there is no CPU fallback")
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.dim, self.n_rows, self.row_base = int(dim), int(n_rows), int(row_base)
+        import ctypes
+        nbytes = ctypes.c_size_t()
+        _native.check(self.lib.emdr2_mips_layout_bytes(max(self.n_rows, 1), self.dim, ctypes.byref(nbytes)), "layout_bytes")
+        self.tiled = torch.zeros(nbytes.value, dtype=torch.uint8, device=self.device)
+        self.emax_sq = torch.zeros(1, dtype=torch.float32, device=self.device)
+        self.ids = None
+        self._ws = None
+        self._xws = None
+        self._filled = 0
+
+    def append_rows(self, rows):
+        """rows: fp16 [n, dim] (numpy or torch, host or device); appended at the next free local row."""
+        if isinstance(rows, np.ndarray):
+            rows = torch.from_numpy(np.ascontiguousarray(rows))
+        if rows.dtype != torch.float16 or rows.dim() != 2 or rows.shape[1] != self.dim:
+            raise ValueError("rows must be float16 [n, %d]" % self.dim)
+        n = rows.shape[0]
+        if self._filled + n > self.n_rows:
+            raise ValueError("shard overflow")
+        for lo in range(0, n, _UPLOAD_ROWS):
+            chunk = rows[lo:lo + _UPLOAD_ROWS].to(self.device, non_blocking=False).contiguous()
+            _native.check(self.lib.emdr2_mips_pack_rows(chunk.data_ptr(), chunk.shape[0], self.dim, self._filled,
+                                                        self.n_rows, self.tiled.data_ptr(), self.emax_sq.data_ptr(),
+                                                        _native.stream_ptr()), "pack_rows")
+            self._filled += chunk.shape[0]
+            torch.cuda.current_stream().synchronize()  # the staging chunk is released next
+        return self
+
+    def set_ids(self, ids):
+        ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)) if not torch.is_tensor(ids) else ids.to(torch.int32)
+        if ids.numel() != self.n_rows:
+            raise ValueError("ids must have one entry per shard row")
+        self.ids = ids.to(self.device).contiguous()
+
+    def _workspace(self, k):
+        import ctypes
+        if self._ws is None:
+            nbytes = ctypes.c_size_t()
+            _native.check(self.lib.emdr2_mips_workspace_bytes(512, self.dim, k, ctypes.byref(nbytes)), "workspace_bytes")
+            self._ws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def search(self, queries, k, exact_fallback=True):
+        """queries fp16 [Q, dim] on this device -> (dist fp16 [Q,k], idx int32, row int64, flags uint32-as-int32)."""
+        if self._filled != self.n_rows:
+            raise RuntimeError("shard not fully populated (%d of %d rows)" % (self._filled, self.n_rows))
+        if queries.dtype != torch.float16 or queries.dim() != 2 or queries.shape[1] != self.dim or not queries.is_cuda:
+            raise ValueError("queries must be a CUDA float16 [Q, %d] tensor" % self.dim)
+        if not (1 <= k <= _native.MAX_TOPK):
+            raise ValueError("top_k must be in [1, %d]" % _native.MAX_TOPK)
+        q = queries.contiguous()
+        nq = q.shape[0]
+        dist = torch.empty((nq, k), dtype=torch.float16, device=self.device)
+        idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        row = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        if self.n_rows == 0:
+            dist.fill_(float('-inf')); idx.fill_(-1); row.fill_(-1)
+            return dist, idx, row, flags
+        ws = self._workspace(k)
+        ids_ptr = self.ids.data_ptr() if self.ids is not None else None
+        _native.check(self.lib.emdr2_mips_search(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base,
+                                                 self.emax_sq.data_ptr(), q.data_ptr(), nq, k, ids_ptr,
+                                                 dist.data_ptr(), idx.data_ptr(), row.data_ptr(), flags.data_ptr(),
+                                                 ws.data_ptr(), ws.numel(), _native.stream_ptr()), "mips_search")
+        if exact_fallback:
+            sel = torch.nonzero(flags).to(torch.int32).flatten()     # one host sync, like the reference's .item() loop
+            if sel.numel():
+                self.search_exact(q, sel, k, dist, idx, row, flags)
+        return dist, idx, row, flags
+
+    def search_exact(self, q, sel, k, dist, idx, row, flags):
+        import ctypes
+        nbytes = ctypes.c_size_t()
+        _native.check(self.lib.emdr2_mips_exact_workspace_bytes(self.n_rows, int(sel.numel()), ctypes.byref(nbytes)), "exact_workspace_bytes")
+        if self._xws is None or self._xws.numel() < nbytes.value:
+            self._xws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        ids_ptr = self.ids.data_ptr() if self.ids is not None else None
+        sel = sel.contiguous()
+        _native.check(self.lib.emdr2_mips_search_exact(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base,
+                                                       q.data_ptr(), q.shape[0], sel.data_ptr(), int(sel.numel()), k, ids_ptr,
+                                                       dist.data_ptr(), idx.data_ptr(), row.data_ptr(), flags.data_ptr(),
+                                                       self._xws.data_ptr(), self._xws.numel(), _native.stream_ptr()),
+                      "mips_search_exact")
+
+    def debug_scores(self, queries):
+        q = queries.contiguous()
+        out = torch.empty((q.shape[0], self.n_rows), dtype=torch.float32, device=self.device)
+        ws = self._workspace(50)
+        _native.check(self.lib.emdr2_mips_debug_scores(self.tiled.data_ptr(), self.n_rows, self.dim, q.data_ptr(), q.shape[0],
+                                                       out.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr()), "debug_scores")
+        return out
+
+    def rows(self, local_row_ids):
+        r = torch.as_tensor(local_row_ids, dtype=torch.int64, device=self.device).contiguous()
+        out = torch.empty((r.numel(), self.dim), dtype=torch.float16, device=self.device)
+        _native.check(self.lib.emdr2_mips_unpack_rows(self.tiled.data_ptr(), self.n_rows, self.dim, r.data_ptr(), r.numel(),
+                                                      out.data_ptr(), _native.stream_ptr()), "unpack_rows")
+        return out
+
+
+def merge_shard_results(dist, idx, row):
+    """[S, Q, k] per-shard canonical lists (device) -> merged [Q, k] via the HIP merge kernel."""
+    lib = _native.lib()
+    s, nq, k = dist.shape
+    od = torch.empty((nq, k), dtype=torch.float16, device=dist.device)
+    oi = torch.empty((nq, k), dtype=torch.int32, device=dist.device)
+    orow = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
+    _native.check(lib.emdr2_mips_merge(dist.contiguous().data_ptr(), idx.contiguous().data_ptr(), row.contiguous().data_ptr(),
+                                       s, nq, k, od.data_ptr(), oi.data_ptr(), orow.data_ptr(), _native.stream_ptr()), "mips_merge")
+    return od, oi, orow
+
+
+class DistributedBruteForceIndex(object):
+    """Exact inner-product top-k over the evidence embeddings (reference: emdr2_index.py:200-305).
+
+    Same constructor and methods as the reference.  `process_group` (extra, optional) selects the
+    ranks that share the index (reference: the MIPS group, mpu/initialize.py:104-142); default is
+    the world group when torch.distributed is initialised, else a single shard.
+    """
+
+    def __init__(self, embed_size, embed_data=None, use_gpu=False, process_group=None):
+        self.embed_size = embed_size
+        self.embed_data = embed_data
+        self.use_gpu = use_gpu
+        self.process_group = process_group
+        self.shard = None
+        self.num_rows = 0
+        self._set_mips_index()
+
+    # -- distributed helpers (overridable in CPU tests) ---------------------------------------------
+    def _world(self):
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_rank(self.process_group), torch.distributed.get_world_size(self.process_group)
+        return 0, 1
+
+    def _make_shard(self, dim, n_rows, row_base):
+        return HipIndexShard(dim, n_rows, row_base)
+
+    def _merge(self, dist, idx, row):
+        return merge_shard_results(dist, idx, row)
+
+    # -- reference API -------------------------------------------------------------------------------
+    def _set_mips_index(self):
+        if self.embed_data is not None:
+            self.add_embed_data(self.embed_data)
+
+    def reset_index(self):
+        self.shard = None
+        if self.embed_data is not None:
+            embed_data_path = self.embed_data.embedding_path
+            del self.embed_data
+            self.embed_data = OpenRetreivalDataStore(embed_data_path)
+        self._set_mips_index()
+
+    def update_index(self):
+        self.shard = None
+        if self.embed_data is not None:
+            self.embed_data.load_from_file()
+        self._set_mips_index()
+
+    def add_embed_data(self, all_embed_data):
+        """Upload this rank's row shard (reference: emdr2_index.py:241-266; there: rank 0 uploads
+        torch.chunk pieces to every visible device)."""
+        ids, rows = all_embed_data.to_arrays()
+        self.add_arrays(ids, rows)
+        all_embed_data.clear()
+
+    def add_arrays(self, ids, rows):
+        if rows.dtype != np.float16 or rows.shape[1] != self.embed_size:
+            raise ValueError("rows must be float16 [N, %d]" % self.embed_size)
+        self.num_rows = rows.shape[0]
+        rank, world = self._world()
+        lo, hi = shard_bounds(self.num_rows, world)[rank]
+        self.shard = self._make_shard(self.embed_size, hi - lo, lo)
+        if hi > lo:
+            self.shard.append_rows(rows[lo:hi])
+            self.shard.set_ids(ids[lo:hi])
+
+    def search_mips_index(self, query_embeds, top_k, reconstruct=True):
+        """(distances fp16 [Q,k], indices int32 [Q,k]) on the device, indices are doc ids
+        (reference: emdr2_index.py:268-305; `reconstruct` is ignored there too).  Every rank passes the
+        same all-gathered query block (emdr2_model.py:438-444) and receives the same result."""
+        if self.shard is None:
+            raise RuntimeError("MIPS Index is not initialized")
+        q = query_embeds
+        if q.dtype != torch.float16:
+            q = q.to(torch.float16)   # reference queries are fp16 under FP16_Module; bf16/fp32 are rounded once
+        dist, idx, row, _ = self.shard.search(q.contiguous(), top_k)
+        rank, world = self._world()
+        if world > 1:
+            dist, idx, row = self._exchange_and_merge(dist, idx, row, world)
+        return dist, idx
+
+    def _exchange_and_merge(self, dist, idx, row, world):
+        nq, k = dist.shape
+        packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+        torch.distributed.all_gather_into_tensor(gathered, packed, group=self.process_group)
+        g_dist = gathered[:, 0].to(torch.int16).view(torch.float16).contiguous()
+        g_idx = gathered[:, 1].to(torch.int32).contiguous()
+        g_row = gathered[:, 2].contiguous()
+        return self._merge(g_dist, g_idx, g_row)

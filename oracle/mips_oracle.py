@@ -178,3 +178,26 @@ def topk_from_scores(score_mat, k, ids=None):
     dist = np.take_along_axis(score_mat, order, axis=1)
     idx = order.astype(np.int32) if ids is None else np.asarray(ids, dtype=np.int32)[order]
     return dist, idx
+
+
+def topk_blas(rows, queries, k, chunk=65536):
+    """The reference's arithmetic on host cores, used as bench.py's timed CPU baseline ("port"):
+    fp32-accumulate GEMM per row chunk (emdr2_index.py:281 runs it in fp16 tensor-core GEMMs), one
+    rounding to fp16, torch.topk per chunk and a running merge (emdr2_index.py:295).  Tie order is
+    torch's; scores are not exact-sum.  Never used as a parity checker."""
+    import torch
+    rows, queries = _f16(rows), _f16(queries)
+    q = torch.from_numpy(queries).float()
+    best_s = best_r = None
+    for lo in range(0, rows.shape[0], chunk):
+        e = torch.from_numpy(rows[lo:lo + chunk]).float()
+        s = (q @ e.T).half().float()
+        v, i = torch.topk(s, min(k, s.shape[1]), dim=1)
+        i = i + lo
+        if best_s is None:
+            best_s, best_r = v, i
+        else:
+            cs, cr = torch.cat([best_s, v], 1), torch.cat([best_r, i], 1)
+            best_s, sel = torch.topk(cs, min(k, cs.shape[1]), dim=1)
+            best_r = torch.gather(cr, 1, sel)
+    return best_s.half().numpy(), best_r.numpy()

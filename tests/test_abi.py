@@ -1,0 +1,69 @@
+"""CPU: the C-ABI library loads and exports every symbol include/emdr2_mips.h declares; argument
+validation works without touching a GPU."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import __graft_entry__ as g
+    from emdr2_amd import _native
+    if not os.path.exists(_native.LIB_PATH):
+        g.build()
+    return _native.lib()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "emdr2_mips.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\bint\s+(emdr2_\w+)\s*\(", text)))
+
+
+def test_every_declared_symbol_is_exported_and_bound(lib):
+    from emdr2_amd import _native
+    names = _declared()
+    assert len(names) >= 12
+    for n in names:
+        assert hasattr(lib, n), "library does not export %s" % n
+        assert n in _native.SIGNATURES, "ctypes binding missing for %s" % n
+    assert sorted(_native.SIGNATURES) == names, "binding table and header drifted"
+
+
+def test_abi_version(lib):
+    assert lib.emdr2_abi_version() == 1
+
+
+def test_layout_bytes_and_argument_validation(lib):
+    n = ctypes.c_size_t()
+    assert lib.emdr2_mips_layout_bytes(21015324, 768, ctypes.byref(n)) == 0
+    assert n.value == ((21015324 + 511) // 512 * 512) * 768 * 2
+    assert lib.emdr2_mips_layout_bytes(10, 100, ctypes.byref(n)) == -1        # dim % 32 != 0
+    assert lib.emdr2_mips_layout_bytes(10, 32, ctypes.byref(n)) == -1         # dim < 64
+    assert lib.emdr2_mips_workspace_bytes(512, 768, 50, ctypes.byref(n)) == 0 and n.value > 512 * 16384 * 8
+    assert lib.emdr2_mips_workspace_bytes(512, 768, 121, ctypes.byref(n)) == -1
+    # null pointers are rejected before any launch
+    assert lib.emdr2_mips_search(None, 10, 768, 0, None, None, 1, 5, None, None, None, None, None, None, 0, None) == -1
+    assert lib.emdr2_mips_merge(None, None, None, 2, 4, 5, None, None, None, None) == -1
+
+
+def test_missing_library_fails_loudly(monkeypatch):
+    from emdr2_amd import _native
+    monkeypatch.setattr(_native, "_lib", None)
+    monkeypatch.setattr(_native, "LIB_PATH", "/nonexistent/libemdr2_hip.so")
+    with pytest.raises(_native.NativeError):
+        _native.lib()
+
+
+def test_index_refuses_to_run_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from emdr2_amd import _native
+    from emdr2_amd.data.emdr2_index import HipIndexShard
+    with pytest.raises(_native.NativeError):
+        HipIndexShard(768, 100, 0)

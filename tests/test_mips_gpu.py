@@ -1,0 +1,195 @@
+"""GPU parity tests for the MIPS path: HIP (through the C ABI) vs the CPU oracle and the golden
+outputs of the reference.  Bar: bit-exact scores and ids (canonical order)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import mips_cases
+from oracle import mips_oracle as mo
+from tests.parity import assert_bit_identical, assert_same_modulo_ties
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _shard(rows, ids=None, row_base=0):
+    from emdr2_amd.data.emdr2_index import HipIndexShard
+    sh = HipIndexShard(rows.shape[1], rows.shape[0], row_base)
+    sh.append_rows(rows)
+    if ids is not None:
+        sh.set_ids(ids)
+    return sh
+
+
+def _search(sh, queries, k, **kw):
+    d, i, r, f = sh.search(torch.from_numpy(queries).cuda(), k, **kw)
+    torch.cuda.synchronize()
+    return d.cpu().numpy(), i.cpu().numpy(), r.cpu().numpy(), f.cpu().numpy()
+
+
+@pytest.mark.parametrize("fn", mips_cases.ALL_CASES)
+def test_golden_cases_bit_identical_to_oracle_and_reference(fn):
+    case = fn()
+    sh = _shard(case["rows"], case["ids"])
+    d, i, r, f = _search(sh, case["queries"], case["k"])
+    assert (f == 0).all()
+    od, oi, orow = mo.topk(case["rows"], case["queries"], case["k"], ids=case["ids"], return_rows=True)
+    assert_bit_identical(d, i, od, oi)
+    assert np.array_equal(r, orow)
+    g = np.load(os.path.join(GOLD, "mips_ref_%s.npz" % case["name"]))
+    assert str(g["digest"]) == mips_cases.digest(case)
+    if case["name"] == "exact_distinct":
+        assert_bit_identical(d, i, g["dist"].view(np.float16), g["idx"])
+    else:
+        assert_same_modulo_ties(d, i, g["dist"].view(np.float16), g["idx"])
+
+
+def test_fast_path_proves_itself_on_realistic_data_and_flags_ties():
+    case = mips_cases.case_realistic()
+    sh = _shard(case["rows"])
+    _, _, _, f = _search(sh, case["queries"], case["k"], exact_fallback=False)
+    assert (f == 0).all(), "realistic data must not need the exact fallback"
+    case = mips_cases.case_exact_ties()
+    sh = _shard(case["rows"])
+    _, _, _, f = _search(sh, case["queries"], case["k"], exact_fallback=False)
+    assert (f != 0).any(), "tie-heavy data must be flagged (boundary bucket not separable)"
+
+
+@pytest.mark.parametrize("n,dim,nq,k", [
+    (1, 64, 1, 1), (37, 64, 3, 50), (127, 96, 5, 7), (129, 768, 2, 50), (2048, 768, 17, 50),
+    (2049, 768, 130, 51), (5000, 128, 600, 20), (3000, 1024, 9, 120), (70000, 256, 64, 101),
+])
+def test_edge_shapes_vs_oracle(n, dim, nq, k):
+    rng = np.random.default_rng(n * 7 + dim + nq)
+    rows = rng.standard_normal((n, dim)).astype(np.float16)
+    q = rng.standard_normal((nq, dim)).astype(np.float16)
+    ids = (rng.permutation(n) + 1).astype(np.int32)
+    sh = _shard(rows, ids, row_base=1000)
+    d, i, r, f = _search(sh, q, k)
+    od, oi, orow = mo.topk(rows, q, k, ids=ids, row_base=1000, return_rows=True)
+    assert (f == 0).all()
+    assert_bit_identical(d, i, od, oi)
+    assert np.array_equal(r, orow)
+
+
+def test_all_three_tile_variants_agree(monkeypatch):
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((9000, 768)).astype(np.float16)
+    q = rng.standard_normal((100, 768)).astype(np.float16)
+    od, oi = mo.topk(rows, q, 50)
+    for v in ("0", "1", "2"):
+        monkeypatch.setenv("EMDR2_MIPS_VARIANT", v)
+        sh = _shard(rows)
+        d, i, _, f = _search(sh, q, 50)
+        assert (f == 0).all()
+        assert_bit_identical(d, i, od, oi)
+
+
+def test_mfma_error_bound_assumption():
+    """|S~ - exact| of the scan's fp32 MFMA accumulation stays far inside the eps the validity proof uses
+    (eps = dim * 2^-22 * ||q|| * max||e||)."""
+    rng = np.random.default_rng(8)
+    rows = (rng.standard_normal((4096, 768)) * 1.5).astype(np.float16)
+    q = (rng.standard_normal((40, 768)) * 1.5).astype(np.float16)
+    sh = _shard(rows)
+    s = sh.debug_scores(torch.from_numpy(q).cuda()).cpu().numpy()
+    exact = q.astype(np.float64) @ rows.astype(np.float64).T
+    err = np.abs(s.astype(np.float64) - exact)
+    qn = np.linalg.norm(q.astype(np.float64), axis=1)[:, None]
+    en = np.linalg.norm(rows.astype(np.float64), axis=1).max()
+    eps = 768 * 2.0 ** -22 * qn * en
+    assert (err <= eps).all()
+    assert err.max() < 0.25 * eps.min(), "bound should be loose, max err %.3g vs eps %.3g" % (err.max(), eps.min())
+
+
+def test_adversarial_row_order_overflows_and_falls_back():
+    """Rows sorted by increasing score make every row beat the running threshold."""
+    rng = np.random.default_rng(13)
+    n, dim = 40000, 64
+    q = np.zeros((2, dim), dtype=np.float16); q[:, 0] = 1
+    rows = (rng.standard_normal((n, dim)) * 0.01).astype(np.float16)
+    rows[:, 0] = (np.arange(n) / 32).astype(np.float16)
+    sh = _shard(rows)
+    d0, i0, _, f0 = _search(sh, q, 50, exact_fallback=False)
+    d, i, _, f = _search(sh, q, 50)
+    od, oi = mo.topk(rows, q, 50)
+    assert (f == 0).all()
+    assert_bit_identical(d, i, od, oi)
+
+
+def test_shard_count_invariance_with_hip_merge():
+    from emdr2_amd.data.emdr2_index import merge_shard_results, shard_bounds
+    case = mips_cases.case_realistic()
+    rows, q, k, ids = case["rows"], case["queries"], case["k"], case["ids"]
+    sh = _shard(rows, ids)
+    d1, i1, r1, _ = _search(sh, q, k)
+    for world in (2, 3, 8):
+        parts = []
+        for lo, hi in shard_bounds(rows.shape[0], world):
+            s = _shard(rows[lo:hi], ids[lo:hi], row_base=lo)
+            parts.append(s.search(torch.from_numpy(q).cuda(), k)[:3])
+        dist = torch.stack([p[0] for p in parts]); idx = torch.stack([p[1] for p in parts]); row = torch.stack([p[2] for p in parts])
+        md, mi, mr = merge_shard_results(dist, idx, row)
+        torch.cuda.synchronize()
+        assert_bit_identical(md.cpu().numpy(), mi.cpu().numpy(), d1, i1)
+        assert np.array_equal(mr.cpu().numpy(), r1)
+
+
+def test_tie_heavy_shards_merge_like_single_search():
+    from emdr2_amd.data.emdr2_index import merge_shard_results, shard_bounds
+    case = mips_cases.case_exact_ties()
+    rows, q, k = case["rows"], case["queries"], case["k"]
+    od, oi = mo.topk(rows, q, k)
+    parts = []
+    for lo, hi in shard_bounds(rows.shape[0], 4):
+        parts.append(_shard(rows[lo:hi], None, row_base=lo).search(torch.from_numpy(q).cuda(), k)[:3])
+    md, mi, _ = merge_shard_results(*[torch.stack([p[j] for p in parts]) for j in range(3)])
+    assert_bit_identical(md.cpu().numpy(), mi.cpu().numpy(), od, oi)
+
+
+def test_unpack_rows_roundtrip():
+    rng = np.random.default_rng(2)
+    rows = rng.standard_normal((1000, 768)).astype(np.float16)
+    sh = _shard(rows)
+    pick = np.array([0, 1, 127, 128, 511, 512, 999])
+    got = sh.rows(pick).cpu().numpy()
+    assert np.array_equal(got.view(np.uint16), rows[pick].view(np.uint16))
+
+
+def test_fast_path_equals_all_exact_path_at_scale():
+    """Size-independent property at a size the CPU oracle cannot reach in seconds: the MFMA fast path
+    and the integer all-exact path (independent arithmetic) return identical results."""
+    gen = torch.Generator(device="cuda").manual_seed(99)
+    n, dim, nq, k = 600_000, 768, 512, 50
+    rows = torch.randn((n, dim), generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+    q = torch.randn((nq, dim), generator=gen, device="cuda", dtype=torch.float32).to(torch.float16)
+    from emdr2_amd.data.emdr2_index import HipIndexShard
+    sh = HipIndexShard(dim, n, 0).append_rows(rows)
+    d, i, r, f = sh.search(q, k, exact_fallback=False)
+    assert int(f.abs().sum()) == 0
+    sel = torch.tensor([0, 77, 511], dtype=torch.int32, device="cuda")
+    d2, i2, r2, f2 = d.clone(), i.clone(), r.clone(), f.clone()
+    d2[sel.long()] = 0; i2[sel.long()] = -7
+    sh.search_exact(q, sel, k, d2, i2, r2, f2)
+    torch.cuda.synchronize()
+    assert torch.equal(d.view(torch.int16), d2.view(torch.int16)) and torch.equal(i, i2) and torch.equal(r, r2)
+    # and the fp32-accumulate CPU port agrees on a slice it can afford (ids of one query, modulo rounding boundaries)
+    dd, rr = mo.topk_fp32accum(rows[:100000].cpu().numpy(), q[:2].cpu().numpy(), k)
+    sh2 = HipIndexShard(dim, 100000, 0).append_rows(rows[:100000])
+    d3, _, r3, _ = sh2.search(q[:2], k)
+    assert (r3.cpu().numpy() == rr).mean() > 0.9
+
+
+def test_index_class_end_to_end_single_rank():
+    from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, OpenRetreivalDataStore
+    case = mips_cases.case_realistic_k100()
+    store = OpenRetreivalDataStore(embedding_path="/tmp/_emdr2_unused.pkl", load_from_path=False, rank=0)
+    store.add_block_data([int(x) for x in case["ids"]], case["rows"])
+    index = DistributedBruteForceIndex(embed_size=768, embed_data=store, use_gpu=True)
+    dist, idx = index.search_mips_index(torch.from_numpy(case["queries"]).cuda(), case["k"], reconstruct=False)
+    assert dist.dtype == torch.float16 and idx.dtype == torch.int32 and idx.is_cuda
+    od, oi = mo.topk(case["rows"], case["queries"], case["k"], ids=case["ids"])
+    assert_bit_identical(dist.cpu().numpy(), idx.cpu().numpy(), od, oi)
+    assert len(store.embed_data) == 0      # reference clears the store after upload (emdr2_index.py:263)
