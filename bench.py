@@ -54,6 +54,10 @@ def synth_rows(lo, hi, seed=1234):
     for c in range(c0, c1):
         g = torch.Generator(device="cuda").manual_seed(seed * 1_000_003 + c)
         block = torch.randn((GEN_CHUNK, DIM), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
+        if os.environ.get("EMDR2_BENCH_DATA") == "zero":      # DVFS experiment only (never a reported number)
+            block.zero_()
+        elif os.environ.get("EMDR2_BENCH_DATA") == "sparse":  # 7/8 of the k-groups zero: low toggle rate, scores stay distinct
+            block.view(-1, DIM // 8, 8)[:, 1:, :] = 0
         a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
         yield block[a - c * GEN_CHUNK: b - c * GEN_CHUNK]
 
@@ -113,8 +117,9 @@ def main():
         dist, idx, row, flags = shard.search(queries, k, exact_fallback=False)
         if world > 1:
             packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
-            gathered = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+            gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)  # concatenated along dim 0
             torch.distributed.all_gather_into_tensor(gathered, packed)
+            gathered = gathered.view(world, 3, nq, k)
             dist, idx, row = merge_shard_results(gathered[:, 0].to(torch.int16).view(torch.float16).contiguous(),
                                                  gathered[:, 1].to(torch.int32).contiguous(), gathered[:, 2].contiguous())
         return dist, idx, flags

@@ -35,6 +35,7 @@ int env_int(const char *name, int dflt)
 }
 
 struct Workspace {
+    char *q_frag;
     char *q_tiled;
     float *qnorm, *tau;
     unsigned *count;
@@ -45,12 +46,13 @@ size_t carve(char *base, int dim, Workspace *w)
 {
     size_t off = 0;
     auto take = [&](size_t bytes) { char *p = base ? base + off : nullptr; off += align_up(bytes, 256); return p; };
+    char *f = take((size_t)(dim / 32) * 512 * 64);
     char *a = take((size_t)(dim / 32) * 512 * 64);
     char *b = take(512 * sizeof(float));
     char *c = take(512 * sizeof(float));
     char *d = take(512 * sizeof(unsigned));
     char *e = take((size_t)512 * CAPQ * sizeof(uint2));
-    if (w) { w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; }
+    if (w) { w->q_frag = f; w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; }
     return off;
 }
 
@@ -134,7 +136,9 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
     const int growth = env_int("EMDR2_MIPS_GROWTH", 32);
     if (seg0 < 512 || seg0 > (int)CAPQ - 512 || growth < 2) return EMDR2_E_BADARG;
     const int force_variant = env_int("EMDR2_MIPS_VARIANT", -1);
-    const int cus = cu_count();
+    const int cus = env_int("EMDR2_MIPS_GRID", cu_count());
+    const int scan_kernel = env_int("EMDR2_MIPS_KERNEL", 1); // 1 = lockstep v1, 2 = ping-pong
+    const int ablate = env_int("EMDR2_MIPS_ABLATE", 0);      // timing experiments only
 
     for (int q0 = 0; q0 < n_q; q0 += EMDR2_MAX_QUERIES_PER_PASS) {
         const int nqp = (n_q - q0) < EMDR2_MAX_QUERIES_PER_PASS ? (n_q - q0) : EMDR2_MAX_QUERIES_PER_PASS;
@@ -144,6 +148,7 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
         const uint16_t *qp = (const uint16_t *)queries + (size_t)q0 * dim;
         int rc;
         if ((rc = mips_launch_pack_queries(qp, nqp, dim, BN, w.q_tiled, w.qnorm, stream))) return rc;
+        if (variant == 0 && scan_kernel == 5 && (rc = mips_launch_pack_queries_frag(qp, nqp, dim, w.q_frag, stream))) return rc;
         const int64_t dense_rows = n_rows < seg0 ? n_rows : seg0;
         if ((rc = mips_launch_init(w.tau, w.count, out_flags + q0, BN, nqp, (unsigned)dense_rows, stream))) return rc;
 
@@ -160,6 +165,8 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
         sp.n_q = nqp;
         sp.capq = CAPQ;
         sp.dense_row0 = 0;
+        sp.tune = env_int("EMDR2_MIPS_TUNE", 1);
+        sp.trace = (unsigned long long *)w.cand + (size_t)511 * CAPQ; // scratch tail of the candidate area (ABL 9 only)
 
         int64_t done = 0, seg_end = dense_rows;
         int64_t next_boundary = (int64_t)seg0 * growth;
@@ -179,7 +186,16 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
                 }
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n], stream) != hipSuccess) return EMDR2_E_LAUNCH;
             }
-            if ((rc = mips_launch_scan(variant, mode, sp, grid, stream))) return rc;
+            if (mode == 0 && variant == 0 && ablate > 0) rc = mips_launch_scan_ablate(ablate, sp, grid, stream);
+            else if (mode == 0 && variant == 0 && scan_kernel == 5) {
+                ScanParams sq = sp;
+                sq.q_tiled = w.q_frag;
+                rc = mips_launch_scan_q8(ablate == 53 ? 3 : 0, sq, grid, stream);
+            }
+            else if (mode == 0 && scan_kernel == 2) rc = mips_launch_scan_pp(variant, 3, sp, grid, stream);
+            else if (mode == 0 && scan_kernel == 4) rc = mips_launch_scan_pp(variant, seg_end == n_rows && done >= n_rows / 16 ? 4 : 3, sp, grid, stream);
+            else rc = mips_launch_scan(variant, mode, sp, grid, stream);
+            if (rc) return rc;
             if (timed) {
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n + 1], stream) != hipSuccess) return EMDR2_E_LAUNCH;
                 g_timing.rows[g_timing.n] = seg_end - done;
@@ -281,6 +297,8 @@ int emdr2_mips_debug_scores(const void *tiled, int64_t n_rows, int dim, const vo
     sp.n_q = n_q;
     sp.capq = CAPQ;
     sp.dense_row0 = 0;
+    sp.tune = 1;
+    sp.trace = nullptr;
     sp.tile_begin = 0;
     sp.tile_end = (int)((n_rows + BM - 1) / BM);
     const int cus = cu_count();

@@ -101,6 +101,26 @@ __global__ void pack_queries_kernel(const uint4 *__restrict__ queries, int n_q, 
     if (lane == 0 && q < n_q) qnorm[q] = sqrtf(s) * 1.001f;
 }
 
+__global__ void pack_queries_frag_kernel(const uint4 *__restrict__ queries, int n_q, int nseg, char *__restrict__ q_frag)
+{
+    const int q = blockIdx.x; // 512 padded query rows, one wave each
+    const int lane0 = threadIdx.x;
+    const int wave = q >> 6, ni = (q >> 5) & 1, l31 = q & 31;
+    for (int seg = lane0; seg < nseg; seg += 64) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (q < n_q) v = queries[(size_t)q * nseg + seg];
+        const int c = seg >> 2, s = seg & 3, ks = s >> 1, hi = s & 1;
+        const int lane = hi * 32 + l31;
+        *(uint4 *)(q_frag + ((((size_t)(c * 8 + wave) * 2 + ks) * 2 + ni) * 64 + lane) * 16) = v;
+    }
+}
+
+int mips_launch_pack_queries_frag(const void *queries, int n_q, int dim, void *q_frag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(pack_queries_frag_kernel, dim3(512), dim3(64), 0, stream, (const uint4 *)queries, n_q, dim / 8, (char *)q_frag);
+    return CHECK_LAUNCH();
+}
+
 int mips_launch_pack_queries(const void *queries, int n_q, int dim, int bn, void *q_tiled, float *qnorm,
                              hipStream_t stream)
 {

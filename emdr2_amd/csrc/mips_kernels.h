@@ -19,10 +19,20 @@ struct ScanParams {
     int n_q;
     unsigned capq;
     int dense_row0;       // MODE 1: first row of the dense segment
+    int tune;             // experiment bits (EMDR2_MIPS_TUNE): 1 = prio on MFMA phase, 2 = prio on load phase, 4 = DMA before reads
+    unsigned long long *trace; // ABL 9: s_memtime stamps [16 chunks][8 waves][10 points]
 };
 
 // variant: 0 = 128 rows x 512 queries, 1 = 256 x 256, 2 = 512 x 128 ; mode: see mips_scan.hip
 int mips_launch_scan(int variant, int mode, const ScanParams &p, int grid, hipStream_t stream);
+// production filter scan, ping-pong wave schedule (mode 0 only)
+int mips_launch_scan_pp(int variant, int depth, const ScanParams &p, int grid, hipStream_t stream);
+// production filter scan for 512 queries, query operand streamed straight to registers (mode 0, variant 0 only)
+int mips_launch_scan_q8(int abl, const ScanParams &p, int grid, hipStream_t stream);
+// fragment-tiled query image for mips_launch_scan_q8: [chunk][wave 8][ks 2][ni 2][lane 64][16 B]
+int mips_launch_pack_queries_frag(const void *queries, int n_q, int dim, void *q_frag, hipStream_t stream);
+// timing experiments (variant 0, mode 0): see ABL in mips_scan.hip
+int mips_launch_scan_ablate(int abl, const ScanParams &p, int grid, hipStream_t stream);
 
 int mips_launch_pack_rows(const void *rows_rm, int64_t n_chunk, int dim, int64_t row_offset, void *tiled,
                           float *emax_sq, hipStream_t stream);

@@ -323,8 +323,9 @@ class DistributedBruteForceIndex(object):
     def _exchange_and_merge(self, dist, idx, row, world):
         nq, k = dist.shape
         packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
-        gathered = torch.empty((world,) + tuple(packed.shape), dtype=torch.int64, device=packed.device)
+        gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)  # concatenated along dim 0
         torch.distributed.all_gather_into_tensor(gathered, packed, group=self.process_group)
+        gathered = gathered.view(world, 3, nq, k)
         g_dist = gathered[:, 0].to(torch.int16).view(torch.float16).contiguous()
         g_idx = gathered[:, 1].to(torch.int32).contiguous()
         g_row = gathered[:, 2].contiguous()

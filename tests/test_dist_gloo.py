@@ -1,0 +1,123 @@
+"""CPU, world_size = 2, gloo: the multi-rank plumbing of DistributedBruteForceIndex (row sharding,
+ONE all-gather of per-shard top-k, deterministic merge, identical result on every rank).  The two GPU
+pieces (local shard search, merge kernel) are replaced by oracle-backed stand-ins here -- tests may use
+the oracle; the product never does."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+class _OracleShard(object):
+    """Stands in for HipIndexShard on CPU: same search() contract, answers from the CPU oracle."""
+
+    def __init__(self, dim, n_rows, row_base):
+        self.dim, self.n_rows, self.row_base = dim, n_rows, row_base
+        self._rows, self.ids = None, None
+
+    def append_rows(self, rows):
+        self._rows = np.ascontiguousarray(rows)
+        return self
+
+    def set_ids(self, ids):
+        self.ids = np.ascontiguousarray(ids, dtype=np.int32)
+
+    def search(self, queries, k):
+        from oracle import mips_oracle as mo
+        q = queries.numpy()
+        if self.n_rows == 0:
+            d = np.full((q.shape[0], k), -np.inf, dtype=np.float16)
+            i = np.full((q.shape[0], k), -1, dtype=np.int32); r = np.full((q.shape[0], k), -1, dtype=np.int64)
+        else:
+            d, i, r = mo.topk(self._rows, q, k, ids=self.ids, row_base=self.row_base, return_rows=True)
+        return torch.from_numpy(d), torch.from_numpy(i), torch.from_numpy(r), torch.zeros(q.shape[0], dtype=torch.int32)
+
+
+def _merge_cpu(dist_t, idx_t, row_t):
+    """(score desc, global row asc) merge of [S, Q, k] lists; the HIP merge kernel's contract."""
+    s, nq, k = dist_t.shape
+    d = dist_t.permute(1, 0, 2).reshape(nq, s * k).numpy()
+    i = idx_t.permute(1, 0, 2).reshape(nq, s * k).numpy()
+    r = row_t.permute(1, 0, 2).reshape(nq, s * k).numpy()
+    key_r = np.where(r < 0, np.iinfo(np.int64).max, r)
+    order = np.lexsort((key_r, -d.astype(np.float32)), axis=1)[:, :k]
+    take = lambda a: torch.from_numpy(np.take_along_axis(a, order, 1).copy())
+    return take(d), take(i), take(r)
+
+
+def _worker(rank, world, port, n_rows, out_dir):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import mips_cases
+    from emdr2_amd.data import emdr2_index as ei
+
+    class Index(ei.DistributedBruteForceIndex):
+        def _make_shard(self, dim, n, base):
+            return _OracleShard(dim, n, base)
+
+        def _merge(self, d, i, r):
+            return _merge_cpu(d, i, r)
+
+    case = mips_cases.case_realistic_k100()
+    rows, ids = case["rows"][:n_rows], case["ids"][:n_rows]
+    index = Index(embed_size=768, embed_data=None, use_gpu=True)
+    index.add_arrays(ids, rows)
+    lo, hi = ei.shard_bounds(n_rows, world)[rank]
+    assert index.shard.n_rows == hi - lo and index.shard.row_base == lo
+    d, i = index.search_mips_index(torch.from_numpy(case["queries"]), 50, reconstruct=False)
+    np.savez(os.path.join(out_dir, "rank%d.npz" % rank), d=d.numpy().view(np.uint16), i=i.numpy())
+    dist.destroy_process_group()
+
+
+def _run(world, n_rows, tmp_path):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, n_rows, str(tmp_path)), nprocs=world, join=True)
+    return [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
+
+
+def test_two_rank_search_equals_single_shard_oracle(tmp_path):
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mips_cases
+    from oracle import mips_oracle as mo
+    case = mips_cases.case_realistic_k100()
+    n_rows = 6000
+    res = _run(2, n_rows, tmp_path)
+    od, oi = mo.topk(case["rows"][:n_rows], case["queries"], 50, ids=case["ids"][:n_rows])
+    for r in res:
+        assert np.array_equal(r["d"], od.view(np.uint16))
+        assert np.array_equal(r["i"], oi)
+
+
+def test_ragged_and_empty_shards(tmp_path):
+    """N not divisible by the world size, and a world larger than N (one rank holds no rows)."""
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import mips_cases
+    from oracle import mips_oracle as mo
+    case = mips_cases.case_realistic_k100()
+    for world, n_rows in ((2, 777), (3, 2)):
+        res = _run(world, n_rows, tmp_path)
+        od, oi = mo.topk(case["rows"][:n_rows], case["queries"], 50, ids=case["ids"][:n_rows])
+        for r in res:
+            assert np.array_equal(r["d"], od.view(np.uint16)) and np.array_equal(r["i"], oi)
+
+
+def test_shard_bounds_follow_torch_chunk():
+    from emdr2_amd.data.emdr2_index import shard_bounds
+    for n in (0, 1, 7, 8, 9, 21015324):
+        for w in (1, 2, 3, 8):
+            b = shard_bounds(n, w)
+            sizes = [hi - lo for lo, hi in b]
+            ref = [c.numel() for c in torch.chunk(torch.empty(n), w)] if n else []
+            assert sizes[:len(ref)] == ref and sum(sizes) == n and all(s == 0 for s in sizes[len(ref):])
+            assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
