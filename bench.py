@@ -154,6 +154,27 @@ def main():
     dom_ms = sum(dom) / len(dom)
     scan_ms_per_step = sum(m for m, _ in launches) / max(args.steps, 1)
 
+    # secondary roofline in the HBM-bound regime (Q = 64, the per-GPU training batch): same index, same kernel family
+    hbm_regime = None
+    if nq > 128:
+        q64 = queries[:64].contiguous()
+        for _ in range(2):
+            shard.search(q64, k, exact_fallback=False)
+        fence()
+        lib.emdr2_mips_set_timing(1)
+        for _ in range(5):
+            shard.search(q64, k, exact_fallback=False)
+        fence()
+        _native.check(lib.emdr2_mips_timing_collect(ms, rows_l, cap, ctypes.byref(n_l)), "timing_collect")
+        lib.emdr2_mips_set_timing(0)
+        l64 = [(ms[i], rows_l[i]) for i in range(n_l.value)]
+        big64 = max(r for _, r in l64)
+        d64 = [m for m, r in l64 if r == big64]
+        ms64 = sum(d64) / len(d64)
+        gb64 = float(big64) * DIM * 2 / (ms64 * 1e-3) / 1e9
+        hbm_regime = {"queries": 64, "bound": "hbm", "achieved": gb64, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                      "frac": gb64 / HBM_PEAK_GBPS, "kernel_ms": ms64, "rows_per_launch": int(big64)}
+
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
@@ -176,6 +197,14 @@ def main():
                     "kernel_ms": dom_ms, "scan_ms_per_step": scan_ms_per_step,
                     "hbm_gbps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS,
                     "mfma_tflops": tflops, "mfma_frac": tflops / MFMA_PEAK_TFLOPS}
+        # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
+        # gfx950 correction + WRITE_SIZE); only quoted when the profile was taken on this exact launch shape.
+        prof = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+        if os.path.exists(prof):
+            pj = json.load(open(prof))
+            if pj.get("algorithmic_bytes_last_segment") == int(bytes_alg) and nq == 512:
+                roofline["traffic"] = pj["traffic_bytes"]
+                roofline["traffic_source"] = "profiles/r01_final_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         result = {
             "metric": "mips_queries_per_sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -188,6 +217,8 @@ def main():
                        "cus": int(lib.emdr2_device_cu_count()), "unproven_queries": flags_total},
             "roofline": roofline,
         }
+        if hbm_regime is not None:
+            result["roofline_hbm_regime"] = hbm_regime
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, queries.cpu().numpy())
         print(json.dumps(result), flush=True)
