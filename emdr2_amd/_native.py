@@ -1,4 +1,4 @@
-"""ctypes binding of libemdr2_hip.so (C ABI: include/emdr2_mips.h).
+"""ctypes binding of libemdr2_hip.so (C ABI: include/emdr2_mips.h, include/emdr2_assembly.h).
 
 The library is built in-tree by `__graft_entry__.build()` / `make -C emdr2_amd/csrc`.  If it is
 missing this module raises at first use -- the product path never falls back to a CPU or eager
@@ -34,6 +34,16 @@ SIGNATURES = {
     "emdr2_mips_set_timing": (_i32, [_i32]),
     "emdr2_mips_timing_collect": (_i32, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i64), _i32, ctypes.POINTER(_i32)]),
 }
+
+SIGNATURES["emdr2_assemble_evidence"] = (_i32, [_vp, _vp, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32,
+                                                  _vp, _vp, _vp, _vp, _vp, _vp])
+
+
+class EvidenceArenaStruct(ctypes.Structure):
+    """include/emdr2_assembly.h: emdr2_evidence_arena (device pointers)."""
+    _fields_ = [("passage_tokens", _vp), ("passage_off", _vp), ("title_tokens", _vp), ("title_off", _vp),
+                ("group_docs", _vp), ("group_off", _vp), ("doc_group", _vp), ("doc_pos", _vp), ("n_docs", _i64)]
+
 
 _lib = None
 

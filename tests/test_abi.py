@@ -19,9 +19,12 @@ def lib():
 
 
 def _declared():
-    text = open(os.path.join(ROOT, "include", "emdr2_mips.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\bint\s+(emdr2_\w+)\s*\(", text)))
+    names = set()
+    for h in sorted(os.listdir(os.path.join(ROOT, "include"))):
+        text = open(os.path.join(ROOT, "include", h)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names |= set(re.findall(r"\bint\s+(emdr2_\w+)\s*\(", text))
+    return sorted(names)
 
 
 def test_every_declared_symbol_is_exported_and_bound(lib):
