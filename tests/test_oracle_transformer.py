@@ -1,0 +1,65 @@
+"""CPU: the torch-fp32 transformer/loss oracle reproduces the reference's own modules (tests/golden/model_ref.npz)."""
+import numpy as np
+import torch
+
+from oracle import transformer_oracle as to
+from tests import model_fixture as mf
+
+TOL = dict(rtol=2e-5, atol=2e-5)
+
+
+def test_masks():
+    g = mf.load()[0]
+    a, b = torch.from_numpy(g["mask_src"]), torch.from_numpy(g["mask_tgt"])
+    assert np.array_equal(to.make_attention_mask_3d(a, b).numpy(), g["mask_3d"])
+    assert np.array_equal(to.make_history_mask_3d(a).numpy(), g["mask_hist"])
+
+
+def test_bert_towers_cls_embedding():
+    g, P, _, _, _, _ = mf.load()
+    ids = torch.from_numpy(g["de_ids"])
+    mask = ~to.make_attention_mask_3d(ids, ids)
+    types = torch.zeros_like(ids)
+    q = to.bert_embed(P, "retriever_model.query_model", mf.CFG, ids, mask, types)
+    c = to.bert_embed(P, "retriever_model.context_model", mf.CFG, ids, mask, types)
+    np.testing.assert_allclose(q.numpy(), g["de_query_emb"], **TOL)
+    np.testing.assert_allclose(c.numpy(), g["de_context_emb"], **TOL)
+
+
+def test_reader_encoder_and_full_logits():
+    g, P, _, _, _, _ = mf.load()
+    enc_ids, dec_ids = torch.from_numpy(g["t5_enc_ids"]), torch.from_numpy(g["t5_dec_ids"])
+    enc = to.t5_encode(P, "language_model", mf.CFG, enc_ids, ~to.make_attention_mask_3d(enc_ids, enc_ids))
+    np.testing.assert_allclose(enc.numpy(), g["t5_enc_out"], **TOL)
+    d_mask = ~(to.make_attention_mask_3d(dec_ids, dec_ids) * to.make_history_mask_3d(dec_ids))
+    logits = to.t5_decode(P, "language_model", mf.CFG, dec_ids, enc, d_mask, ~to.make_attention_mask_3d(dec_ids, enc_ids))
+    np.testing.assert_allclose(logits.numpy(), g["t5_logits"], rtol=1e-4, atol=1e-4)
+
+
+def test_emdr2_forward_loss_and_gradients():
+    g, P, grads, meta, passages, titles = mf.load()
+    ctx, typ, ext, one = mf.assembled_inputs(g, meta, passages, titles)
+    P = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    qb = torch.from_numpy(g["e_query_ids"])
+    lm_logits, tlp, one_logits = to.emdr2_forward(P, mf.CFG, qb, torch.zeros_like(qb), ~to.make_attention_mask_3d(qb, qb), ctx, typ, ext, one,
+                                                  torch.from_numpy(g["e_dec_ids"]))
+    np.testing.assert_allclose(lm_logits.detach().numpy(), g["e_lm_logits"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(tlp.detach().numpy(), g["e_topk_log_probs"], rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(one_logits.numpy(), g["e_one_context_logits"], rtol=1e-4, atol=1e-4)
+    labels, loss_mask = torch.from_numpy(g["e_labels"]), torch.from_numpy(g["e_loss_mask"])
+    lm_loss = to.reader_ce_loss(lm_logits, labels, loss_mask)
+    r_loss, util, null = to.retriever_loss_and_utility(one_logits, tlp, labels, loss_mask, meta["eos"])
+    np.testing.assert_allclose([lm_loss.item(), r_loss.item(), util.item(), null.item()], g["e_losses"], rtol=1e-5, atol=1e-6)
+    (lm_loss + r_loss).backward()
+    worst = 0.0
+    for k, ref in grads.items():
+        got = P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])
+        worst = max(worst, float((got - ref).abs().max()))
+        np.testing.assert_allclose(got.numpy(), ref.numpy(), rtol=2e-3, atol=2e-6, err_msg=k)
+    assert worst < 1e-3
+
+
+def test_learning_rate_table():
+    g = mf.load()[0]
+    ours = [to.annealing_lr(i + 1, 2e-5, 10, 1000) for i in range(1000)]
+    np.testing.assert_allclose(ours, g["lr_table"], rtol=1e-12, atol=0)
