@@ -39,6 +39,30 @@ SIGNATURES["emdr2_assemble_evidence"] = (_i32, [_vp, _vp, _i32, _i32, _i32, _vp,
                                                   _vp, _vp, _vp, _vp, _vp, _vp])
 
 
+_f32 = ctypes.c_float
+SIGNATURES["emdr2_gemm_nt_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _i64,
+                                             _f32, _vp, _i32, _vp, _vp, _i32, _vp])
+SIGNATURES["emdr2_transpose_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _vp, _vp])
+
+
+SIGNATURES.update({
+    "emdr2_layernorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "emdr2_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_softmax_mask_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "emdr2_softmax_mask_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "emdr2_softmax_mask_t": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "emdr2_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "emdr2_embedding_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "emdr2_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "emdr2_lse_gather_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_lse_gather_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),
+    "emdr2_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp]),
+    "emdr2_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
+    "emdr2_accum_bf16_to_f32": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+})
+
+
 class EvidenceArenaStruct(ctypes.Structure):
     """include/emdr2_assembly.h: emdr2_evidence_arena (device pointers)."""
     _fields_ = [("passage_tokens", _vp), ("passage_off", _vp), ("title_tokens", _vp), ("title_off", _vp),

@@ -1,0 +1,483 @@
+// emdr2_amd/csrc/elementwise.hip -- HBM-bound kernels around the GEMMs (include/emdr2_ops.h).
+#include "../../include/emdr2_ops.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace {
+
+__device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f2bf(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+// 64 x 64 tiles through LDS (+1 padding), 256 threads: coalesced 128-B rows in, 128-B rows out
+__global__ void __launch_bounds__(256) transpose_kernel(const uint16_t *in, long long ld_in, uint16_t *out, long long ld_out, int rows,
+                                                        int cols, int batch2, long long sI1, long long sO1, long long sI2, long long sO2,
+                                                        float *colsum)
+{
+    __shared__ uint16_t tile[64][66];
+    const int b1 = blockIdx.z / batch2, b2 = blockIdx.z % batch2;
+    in += b1 * sI1 + b2 * sI2;
+    out += b1 * sO1 + b2 * sO2;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    float cs = 0.f;
+    for (int i = ty; i < 64; i += 4) {
+        const int r = r0 + i, c = c0 + tx;
+        uint16_t v = 0;
+        if (r < rows && c < cols) v = in[(long long)r * ld_in + c];
+        tile[i][tx] = v;
+        cs += bf2f(v);
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+        const int c = c0 + i, r = r0 + tx;
+        if (c < cols && r < rows) out[(long long)c * ld_out + r] = tile[tx][i];
+    }
+    if (colsum) {
+        __shared__ float part[4][64];
+        part[ty][tx] = cs;
+        __syncthreads();
+        if (ty == 0 && c0 + tx < cols) atomicAdd(&colsum[c0 + tx], part[0][tx] + part[1][tx] + part[2][tx] + part[3][tx]);
+    }
+}
+
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v)
+{
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// ---- LayerNorm (torch.nn.LayerNorm semantics, eps inside the sqrt; mpu/layers.py:28-36) -----------------------
+// one wave per row, H % 8 == 0, 16-B vector loads
+__global__ void __launch_bounds__(256) layernorm_fwd_kernel(const uint16_t *x, const float *gamma, const float *beta, uint16_t *y,
+                                                            float *mean, float *rstd, long long rows, int H, float eps)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const uint16_t *xr = x + row * H;
+    float s = 0.f, ss = 0.f;
+    for (int i = lane * 8; i < H; i += 512) {
+        const uint4 v = *(const uint4 *)(xr + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float a = bf2f((uint16_t)(w[j] & 0xffff)), b = bf2f((uint16_t)(w[j] >> 16)); s += a + b; ss += a * a + b * b; }
+    }
+    s = wave_sum(s); ss = wave_sum(ss);
+    const float mu = s / H;
+    const float var = fmaxf(ss / H - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
+    if (lane == 0) { mean[row] = mu; rstd[row] = rs; }
+    uint16_t *yr = y + row * H;
+    for (int i = lane * 8; i < H; i += 512) {
+        const uint4 v = *(const uint4 *)(xr + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float a = (bf2f((uint16_t)(w[j] & 0xffff)) - mu) * rs * gamma[i + 2 * j] + beta[i + 2 * j];
+            const float b = (bf2f((uint16_t)(w[j] >> 16)) - mu) * rs * gamma[i + 2 * j + 1] + beta[i + 2 * j + 1];
+            o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+        }
+        *(uint4 *)(yr + i) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional residual-branch gradient added on the way out;
+// dgamma/dbeta: per-block partial sums in LDS, one atomicAdd per column per block
+__global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t *dy, const uint16_t *x, const float *gamma, const float *mean,
+                                                            const float *rstd, const uint16_t *dres, uint16_t *dx, float *dgamma,
+                                                            float *dbeta, long long rows, int H, int rows_per_block)
+{
+    extern __shared__ float part[]; // [2][H]
+    for (int i = threadIdx.x; i < 2 * H; i += 256) part[i] = 0.f;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    for (long long row = r0 + wave; row < r0 + rows_per_block && row < rows; row += 4) {
+        const uint16_t *xr = x + row * H, *gr = dy + row * H;
+        const float mu = mean[row], rs = rstd[row];
+        float s1 = 0.f, s2 = 0.f;
+        for (int i = lane; i < H; i += 64) {
+            const float xh = (bf2f(xr[i]) - mu) * rs, g = bf2f(gr[i]) * gamma[i];
+            s1 += g; s2 += g * xh;
+        }
+        s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
+        for (int i = lane; i < H; i += 64) {
+            const float xh = (bf2f(xr[i]) - mu) * rs, d = bf2f(gr[i]);
+            float v = rs * (d * gamma[i] - s1 - xh * s2);
+            if (dres) v += bf2f(dres[row * H + i]);
+            dx[row * H + i] = f2bf(v);
+            atomicAdd(&part[i], d * xh);
+            atomicAdd(&part[H + i], d);
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < H; i += 256) { atomicAdd(&dgamma[i], part[i]); atomicAdd(&dbeta[i], part[H + i]); }
+}
+
+// ---- masked softmax over the last dim (reference fallback path: fused_softmax.py:113-125, mask value -10000 REPLACES the score) --
+// masked(b, q, k) = ids_q[b,q] == 0 || ids_k[b,k] == 0 || (causal && k > q)     (mask_creation_utils.py:17-42, pad id 0)
+// scores [B, np, sq, sk] bf16 in place -> probs; stats m, l fp32 [B, np, sq] (row max and sum of exp), one wave per row
+__global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const long long *ids_q, const long long *ids_k, int np, int sq, int sk,
+                                                          int causal, float *mstat, float *lstat, long long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % sq);
+    const long long b = row / ((long long)sq * np);
+    const bool qpad = ids_q[b * sq + q] == 0;
+    uint16_t *sr = s + row * sk;
+    const long long *kid = ids_k + b * sk;
+    float m = -3.0e38f;
+    for (int k = lane; k < sk; k += 64) {
+        const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+        m = fmaxf(m, masked ? -10000.f : bf2f(sr[k]));
+    }
+    m = wave_max(m);
+    float l = 0.f;
+    for (int k = lane; k < sk; k += 64) {
+        const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+        l += __expf((masked ? -10000.f : bf2f(sr[k])) - m);
+    }
+    l = wave_sum(l);
+    const float inv = 1.f / l;
+    for (int k = lane; k < sk; k += 64) {
+        const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+        sr[k] = f2bf(__expf((masked ? -10000.f : bf2f(sr[k])) - m) * inv);
+    }
+    if (lane == 0 && mstat) { mstat[row] = m; lstat[row] = l; }
+}
+
+// dS = P * (dP - sum_k P*dP), in place on dP; masked positions get the same formula (their P is ~0 unless the row is fully
+// masked, where the reference's autograd also flows a uniform-softmax gradient into the replaced (constant) scores: those
+// are zeroed because masked_fill breaks the dependence on the score).  D[row] is also written.
+__global__ void __launch_bounds__(256) softmax_bwd_kernel(const uint16_t *p, uint16_t *dp, const long long *ids_q, const long long *ids_k,
+                                                          int np, int sq, int sk, int causal, float *dstat, long long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % sq);
+    const long long b = row / ((long long)sq * np);
+    const bool qpad = ids_q[b * sq + q] == 0;
+    const long long *kid = ids_k + b * sk;
+    const uint16_t *pr = p + row * sk;
+    uint16_t *dr = dp + row * sk;
+    float d = 0.f;
+    for (int k = lane; k < sk; k += 64) d += bf2f(pr[k]) * bf2f(dr[k]);
+    d = wave_sum(d);
+    for (int k = lane; k < sk; k += 64) {
+        const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+        dr[k] = masked ? (uint16_t)0 : f2bf(bf2f(pr[k]) * (bf2f(dr[k]) - d));
+    }
+    if (lane == 0 && dstat) dstat[row] = d;
+}
+
+// transposed twin used by the attention backward: from raw scaled scores S^T [B, np, sk, sq] and dP^T, with the forward's
+// row statistics m, l and D (all indexed [B, np, sq]): P^T = exp(s - m[q]) / l[q] (masked: exp(-10000 - m[q]) / l[q]),
+// dS^T = masked ? 0 : P^T * (dP^T - D[q]).  Writes P^T over S^T and dS^T over dP^T.  Elementwise, 8 elements per thread.
+__global__ void __launch_bounds__(256) softmax_t_kernel(uint16_t *st, uint16_t *dpt, const long long *ids_q, const long long *ids_k,
+                                                        const float *mstat, const float *lstat, const float *dstat, int np, int sq,
+                                                        int sk, int causal, long long total)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= total) return;
+    const int q = (int)(i % sq);
+    const long long rk = i / sq;             // (b, n, k)
+    const int k = (int)(rk % sk);
+    const long long bn = rk / sk;
+    const long long b = bn / np;
+    const long long srow = bn * sq + q;      // stats index
+    const bool masked = ids_q[b * sq + q] == 0 || ids_k[b * sk + k] == 0 || (causal && k > q);
+    const float pt = __expf((masked ? -10000.f : bf2f(st[i])) - mstat[srow]) / lstat[srow];
+    st[i] = f2bf(pt);
+    dpt[i] = masked ? (uint16_t)0 : f2bf(pt * (bf2f(dpt[i]) - dstat[srow]));
+}
+
+// ---- GELU backward on the saved pre-activation (exact erf form; transformer.py:80,103-104) -------------------------------
+__global__ void __launch_bounds__(256) gelu_bwd_kernel(const uint16_t *pre, const uint16_t *dact, uint16_t *dpre, long long n)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const uint4 a = *(const uint4 *)(pre + i), g = *(const uint4 *)(dact + i);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float r[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const float u = bf2f((uint16_t)(h ? aw[j] >> 16 : aw[j] & 0xffff)), d = bf2f((uint16_t)(h ? gw[j] >> 16 : gw[j] & 0xffff));
+            const float cdf = 0.5f * (1.f + erff(u * 0.70710678118654752f));
+            r[h] = d * (cdf + u * 0.3989422804014327f * __expf(-0.5f * u * u));
+        }
+        o[j] = (uint32_t)f2bf(r[0]) | ((uint32_t)f2bf(r[1]) << 16);
+    }
+    *(uint4 *)(dpre + i) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+
+// ---- embedding (language_model.py:169-181): out = W[ids] + P[pos] (+ T[types]) ------------------------------------------------
+__global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids, const long long *types, const uint16_t *W, const uint16_t *P,
+                                                            const uint16_t *T, uint16_t *out, long long tokens, int S, int H)
+{
+    const long long t = blockIdx.x;
+    const long long id = ids[t], pos = t % S;
+    const long long ty = types ? types[t] : 0;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        float v = bf2f(W[id * H + i]) + bf2f(P[pos * H + i]);
+        if (types) v += bf2f(T[ty * H + i]);
+        out[t * H + i] = f2bf(v);
+    }
+}
+
+__global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids, const long long *types, const uint16_t *dout, float *dW, float *dP,
+                                                            float *dT, long long tokens, int S, int H)
+{
+    const long long t = blockIdx.x;
+    const long long id = ids[t], pos = t % S;
+    const long long ty = types ? types[t] : 0;
+    for (int i = threadIdx.x; i < H; i += 256) {
+        const float g = bf2f(dout[t * H + i]);
+        atomicAdd(&dW[id * H + i], g);
+        atomicAdd(&dP[pos * H + i], g);
+        if (types) atomicAdd(&dT[ty * H + i], g);
+    }
+}
+
+// ---- log-softmax + gather over the vocabulary (train_e2eqa.py:72-123,152-160) --------------------------------------------------
+// gold[row] = logits[row, label[row]] - logsumexp(logits[row, :]),  lse[row] kept for the backward; one block per row
+__global__ void __launch_bounds__(256) lse_gather_kernel(const uint16_t *logits, const long long *labels, float *gold, float *lse, int V)
+{
+    __shared__ float red[4];
+    const long long row = blockIdx.x;
+    const uint16_t *lr = logits + row * V;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float m = -3.0e38f;
+    for (int i = threadIdx.x; i < V; i += 256) m = fmaxf(m, bf2f(lr[i]));
+    m = wave_max(m);
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float s = 0.f;
+    for (int i = threadIdx.x; i < V; i += 256) s += __expf(bf2f(lr[i]) - m);
+    s = wave_sum(s);
+    if (lane == 0) red[wave] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float l = m + __logf(red[0] + red[1] + red[2] + red[3]);
+        lse[row] = l;
+        gold[row] = bf2f(lr[labels[row]]) - l;
+    }
+}
+
+// dlogits[row, v] = w[row] * (onehot(label) - softmax)[v]  where w = d(loss)/d(gold[row])
+__global__ void __launch_bounds__(256) lse_gather_bwd_kernel(const uint16_t *logits, const long long *labels, const float *lse, const float *w,
+                                                             uint16_t *dlogits, int V)
+{
+    const long long row = blockIdx.x;
+    const float l = lse[row], ww = w[row];
+    const long long lab = labels[row];
+    for (int i = threadIdx.x; i < V; i += 256) {
+        const float sm = __expf(bf2f(logits[row * V + i]) - l);
+        dlogits[row * V + i] = f2bf(ww * ((i == lab ? 1.f : 0.f) - sm));
+    }
+}
+
+// ---- optimizer: fp32 masters, decoupled weight decay Adam (apex FusedAdam defaults, training.py:89; SURVEY 8c: unpinned) -------
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, long long n, float *out)
+{
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+}
+
+__global__ void __launch_bounds__(256) adam_kernel(float *master, const float *grad, float *m, float *v, uint16_t *param_bf16, long long n, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2, const float *gnorm_sq,
+                                                   float clip)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float scale = 1.f;
+    if (gnorm_sq && clip > 0.f) { const float gn = sqrtf(*gnorm_sq); const float c = clip / (gn + 1.0e-6f); if (c < 1.f) scale = c; }
+    const float g = grad[i] * scale;
+    const float mi = b1 * m[i] + (1.f - b1) * g;
+    const float vi = b2 * v[i] + (1.f - b2) * g * g;
+    m[i] = mi; v[i] = vi;
+    const float upd = (mi / bc1) / (sqrtf(vi / bc2) + eps) + wd * master[i];
+    const float w = master[i] - lr * upd;
+    master[i] = w;
+    if (param_bf16) param_bf16[i] = f2bf(w);
+}
+
+__global__ void __launch_bounds__(256) cast_kernel(const float *src, uint16_t *dst, long long n)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = f2bf(src[i]);
+}
+
+__global__ void __launch_bounds__(256) accum_bf16_to_f32_kernel(const uint16_t *src, float *dst, long long n, float scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] += scale * bf2f(src[i]);
+}
+
+} // namespace
+
+extern "C" int emdr2_transpose_bf16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int rows, int cols, int batch1,
+                                    int64_t sI1, int64_t sO1, int batch2, int64_t sI2, int64_t sO2, float *colsum, void *stream)
+{
+    if (!in || !out || rows < 1 || cols < 1 || batch1 < 1 || batch2 < 1) return -1;
+    dim3 grid((cols + 63) / 64, (rows + 63) / 64, batch1 * batch2);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)in, (long long)ld_in, (uint16_t *)out,
+                       (long long)ld_out, rows, cols, batch2, (long long)sI1, (long long)sO1, (long long)sI2, (long long)sO2, colsum);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+#define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -3)
+
+extern "C" int emdr2_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, int64_t rows,
+                                   int H, float eps, void *stream)
+{
+    if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 1 || H < 8 || (H & 7)) return -1;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, gamma, beta,
+                       (uint16_t *)y, mean, rstd, (long long)rows, H, eps);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres,
+                                   void *dx, float *dgamma, float *dbeta, int64_t rows, int H, void *stream)
+{
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 1 || H < 1 || H > 8192) return -1;
+    const int rpb = 64;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream,
+                       (const uint16_t *)dy, (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta,
+                       (long long)rows, H, rpb);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_softmax_mask_fwd(void *scores, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int causal,
+                                      float *m, float *l, void *stream)
+{
+    if (!scores || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
+    const long long rows = (long long)batch * heads * sq;
+    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores,
+                       (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq,
+                                      int sk, int causal, float *d, void *stream)
+{
+    if (!probs || !dprobs || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
+    const long long rows = (long long)batch * heads * sq;
+    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs,
+                       (uint16_t *)dprobs, (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l,
+                                    const float *d, int batch, int heads, int sq, int sk, int causal, void *stream)
+{
+    if (!scores_t || !dprobs_t || !ids_q || !ids_k || !m || !l || !d || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
+    const long long total = (long long)batch * heads * sq * sk;
+    hipLaunchKernelGGL(softmax_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores_t,
+                       (uint16_t *)dprobs_t, (const long long *)ids_q, (const long long *)ids_k, m, l, d, heads, sq, sk, causal, total);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int64_t n, void *stream)
+{
+    if (!pre || !dact || !dpre || n < 8 || (n & 7)) return -1;
+    hipLaunchKernelGGL(gelu_bwd_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)pre,
+                       (const uint16_t *)dact, (uint16_t *)dpre, (long long)n);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, const void *W, const void *P, const void *T, void *out, int64_t tokens,
+                                   int S, int H, void *stream)
+{
+    if (!ids || !W || !P || !out || tokens < 1 || S < 1 || H < 1 || (types && !T)) return -1;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
+                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)tokens, S, H);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S,
+                                   int H, void *stream)
+{
+    if (!ids || !dout || !dW || !dP || tokens < 1 || S < 1 || H < 1 || (types && !dT)) return -1;
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
+                       (const uint16_t *)dout, dW, dP, dT, (long long)tokens, S, H);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_lse_gather_fwd(const void *logits, const int64_t *labels, float *gold, float *lse, int64_t rows, int V, void *stream)
+{
+    if (!logits || !labels || !gold || !lse || rows < 1 || V < 1) return -1;
+    hipLaunchKernelGGL(lse_gather_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)logits, (const long long *)labels,
+                       gold, lse, V);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_lse_gather_bwd(const void *logits, const int64_t *labels, const float *lse, const float *w, void *dlogits, int64_t rows, int V,
+                                    void *stream)
+{
+    if (!logits || !labels || !lse || !w || !dlogits || rows < 1 || V < 1) return -1;
+    hipLaunchKernelGGL(lse_gather_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)logits,
+                       (const long long *)labels, lse, w, (uint16_t *)dlogits, V);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_sumsq_f32(const float *g, int64_t n, float *out, void *stream)
+{
+    if (!g || !out || n < 1) return -1;
+    int blocks = (int)((n + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long long)n, out);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_adam_step(float *master, const float *grad, float *m, float *v, void *param_bf16, int64_t n, float lr, float beta1, float beta2,
+                               float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream)
+{
+    if (!master || !grad || !m || !v || n < 1 || step < 1) return -1;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, master, grad, m, v, (uint16_t *)param_bf16,
+                       (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, clip);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream)
+{
+    if (!src || !dst || n < 1) return -1;
+    hipLaunchKernelGGL(cast_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, src, (uint16_t *)dst, (long long)n);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_accum_bf16_to_f32(const void *src, float *dst, int64_t n, float scale, void *stream)
+{
+    if (!src || !dst || n < 1) return -1;
+    hipLaunchKernelGGL(accum_bf16_to_f32_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)src, dst,
+                       (long long)n, scale);
+    return LAUNCH_OK();
+}

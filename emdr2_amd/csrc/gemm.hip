@@ -1,0 +1,199 @@
+// emdr2_amd/csrc/gemm.hip -- bf16 MFMA GEMM, "NT" form, with fused epilogues (include/emdr2_ops.h).
+//
+//   C[m, n] = epilogue( alpha * sum_k A[m, k] * B[n, k] )         A: [M, K] row-major (lda), B: [N, K] row-major (ldb)
+//
+// This is the shape of every linear layer of the reference (F.linear: weight is [out, in],
+// megatron/mpu/layers.py:255,353), of QK^T (transformer.py:309-312) and - with pre-transposed operands - of every
+// backward GEMM.  Same engine as the index scan (mips_scan.hip): 8 waves, wave tile 64 x 128 = 2x4
+// v_mfma_f32_32x32x16_bf16 accumulators, operands staged through a 3-deep LDS ring by LDS-DMA in 16-row x 64-B
+// pieces whose 16-B groups are XOR-swizzled on the SOURCE address (conflict-free ds_read_b128), counted vmcnt.
+// Epilogue: alpha, + bias[n], exact-erf GELU (optionally also storing the pre-activation for the backward),
+// + residual[m, n], bf16 or fp32 output.  Two batch levels with independent strides cover [batch, head] attention GEMMs.
+#include "../../include/emdr2_ops.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+#define GNST 3
+
+struct GemmParams {
+    const char *A, *B;
+    char *C, *C2;             // C2: optional pre-activation output (bf16)
+    const float *bias;
+    const char *R;            // optional residual (bf16, same indexing as C)
+    long long lda, ldb, ldc;  // in elements
+    long long sA1, sB1, sC1, sA2, sB2, sC2; // batch strides in elements
+    int M, N, K, batch2;
+    float alpha;
+    int gelu, out_f32;
+};
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)
+{
+    uint32_t u = __float_as_uint(f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); // quiet NaN
+    u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
+    return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+
+template <int WM, int WN>
+__global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
+{
+    constexpr int BM = WM * 64, BN = WN * 128;
+    constexpr int A_STAGE = BM * 64, B_STAGE = BN * 64, STAGE = A_STAGE + B_STAGE;
+    constexpr int A_PW = BM / 128, B_PW = BN / 128, PPW = A_PW + B_PW;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int swz = (l31 >> 2) & 3;
+
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const int b1 = blockIdx.z / p.batch2, b2 = blockIdx.z % p.batch2;
+    const char *A = p.A + ((long long)b1 * p.sA1 + (long long)b2 * p.sA2) * 2;
+    const char *B = p.B + ((long long)b1 * p.sB1 + (long long)b2 * p.sB2) * 2;
+    const long long coff = (long long)b1 * p.sC1 + (long long)b2 * p.sC2;
+
+    int a_off[2], b_off[2];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const int sp = ((ks * 2 + hi) ^ swz) << 4;
+        a_off[ks] = (wm * 64 + l31) * 64 + sp;
+        b_off[ks] = A_STAGE + (wn * 128 + l31) * 64 + sp;
+    }
+
+    // LDS-DMA source addresses: piece = 16 rows x 64 B; lane -> (row = lane>>2, LDS slot = lane&3), source group = slot ^ swizzle(row)
+    const int prow = lane >> 2, pslot = lane & 3;
+    const char *a_src[A_PW];
+    const char *b_src[B_PW];
+#pragma unroll
+    for (int j = 0; j < A_PW; ++j) {
+        const int r = (wave + 8 * j) * 16 + prow;                   // row inside the tile
+        int gm = m0 + r; if (gm >= p.M) gm = p.M - 1;               // overhang rows re-read the last row (never stored)
+        a_src[j] = A + ((long long)gm * p.lda + ((pslot ^ ((r >> 2) & 3)) << 3)) * 2;
+    }
+#pragma unroll
+    for (int j = 0; j < B_PW; ++j) {
+        const int r = (wave + 8 * j) * 16 + prow;
+        int gn = n0 + r; if (gn >= p.N) gn = p.N - 1;
+        b_src[j] = B + ((long long)gn * p.ldb + ((pslot ^ ((r >> 2) & 3)) << 3)) * 2;
+    }
+
+    const int nch = p.K >> 5;
+    int pf_c = 0, pf_stage = 0;
+    auto issue = [&]() {
+        const int c = pf_c < nch ? pf_c : nch - 1;                  // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
+        char *sb = smem + pf_stage * STAGE;
+#pragma unroll
+        for (int j = 0; j < A_PW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(a_src[j] + c * 64), (lptr_t *)(sb + (wave + 8 * j) * 1024), 16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < B_PW; ++j)
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b_src[j] + c * 64), (lptr_t *)(sb + A_STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+        ++pf_c;
+        pf_stage = (pf_stage == GNST - 1) ? 0 : pf_stage + 1;
+    };
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    issue();
+    issue();
+    int cs = 0;
+    for (int c = 0; c < nch; ++c) {
+        if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        issue();
+        const char *sb = smem + cs * STAGE;
+        cs = (cs == GNST - 1) ? 0 : cs + 1;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            bf16x8 a[2], b[4];
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8 *)(sb + a_off[ks] + mi * 2048);
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8 *)(sb + b_off[ks] + ni * 2048);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two speculative chunks
+
+    // epilogue.  C layout of the 32x32 MFMA: column n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    const int mrow0 = m0 + wm * 64 + 4 * hi;
+    const int ncol0 = n0 + wn * 128 + l31;
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = ncol0 + ni * 32;
+        if (n >= p.N) continue;
+        const float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
+                if (m >= p.M) continue;
+                const long long o = coff + (long long)m * p.ldc + n;
+                float v = acc[mi][ni][r] * p.alpha + bias;
+                if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
+                if (p.gelu) v = gelu_erf(v);
+                if (p.R) v += bf16_to_f32(((const uint16_t *)p.R)[o]);
+                if (p.out_f32) ((float *)p.C)[o] = v;
+                else ((uint16_t *)p.C)[o] = f32_to_bf16(v);
+            }
+        }
+    }
+}
+
+template <int WM, int WN>
+static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
+{
+    constexpr int BM = WM * 64, BN = WN * 128;
+    constexpr int LDS = GNST * (BM + BN) * 64;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        attr_done = true;
+    }
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN>), grid, dim3(512), LDS, stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
+                                  int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
+                                  float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
+                                  void *stream)
+{
+    if (!A || !B || !C || M < 1 || N < 1 || K < 32 || (K & 31) || batch1 < 1 || batch2 < 1) return -1;
+    if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return -1;
+    if ((sA1 & 7) || (sB1 & 7) || (sA2 & 7) || (sB2 & 7)) return -1;
+    GemmParams p;
+    p.A = (const char *)A; p.B = (const char *)B; p.C = (char *)C; p.C2 = (char *)pre_act;
+    p.bias = bias; p.R = (const char *)residual;
+    p.lda = lda; p.ldb = ldb; p.ldc = ldc;
+    p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
+    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32;
+    const int batch = batch1 * batch2;
+    if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
+    if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);
+    return launch_gemm<4, 2>(p, batch, (hipStream_t)stream);
+}

@@ -1,0 +1,339 @@
+"""Thin torch-tensor wrappers over the C ABI of include/emdr2_ops.h (libemdr2_hip.so) and the autograd glue that
+chains them.  No torch compute lives here: every FLOP and every byte moved on the model path goes through a hand-written HIP
+kernel; torch provides storage, views, the autograd tape and streams.  There is no CPU fallback (a missing library raises)."""
+import math
+
+import torch
+
+from emdr2_amd import _native
+
+BF16 = torch.bfloat16
+
+
+def _lib():
+    return _native.lib()
+
+
+def _sp():
+    return _native.stream_ptr()
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+def _check_bf16(*ts):
+    for t in ts:
+        if t is not None and (t.dtype != BF16 or not t.is_cuda):
+            raise TypeError("expected a CUDA bfloat16 tensor")
+
+
+# ---- raw kernels --------------------------------------------------------------------------------------------------------
+def gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None,
+            gelu=False, pre_act=None, residual=None):
+    _native.check(_lib().emdr2_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, batch1, sA1, sB1, sC1, batch2, sA2,
+                                            sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual),
+                                            int(C.dtype == torch.float32), _sp()), "gemm_nt_bf16")
+    return C
+
+
+def matmul_nt(a, b, out_dtype=BF16, **kw):
+    """a [M, K] @ b[N, K]^T for contiguous 2-D bf16 operands."""
+    M, K = a.shape
+    N = b.shape[0]
+    c = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    return gemm_nt(a, K, b, K, c, N, M, N, K, **kw)
+
+
+def transpose(x2d, colsum=None):
+    """[R, C] bf16 contiguous -> [C, R]; optional fp32 column sums accumulated into `colsum`."""
+    R, C = x2d.shape
+    out = torch.empty((C, R), dtype=BF16, device=x2d.device)
+    _native.check(_lib().emdr2_transpose_bf16(x2d.data_ptr(), C, out.data_ptr(), R, R, C, 1, 0, 0, 1, 0, 0, _ptr(colsum), _sp()), "transpose")
+    return out
+
+
+def head_transpose(x, b, s, heads, hn):
+    """x: strided view [b, s, heads, hn] (last dim contiguous) -> contiguous [b, heads, hn, s]."""
+    ld = x.stride(1)
+    out = torch.empty((b, heads, hn, s), dtype=BF16, device=x.device)
+    _native.check(_lib().emdr2_transpose_bf16(x.data_ptr(), ld, out.data_ptr(), s, s, hn, b, x.stride(0), heads * hn * s, heads, x.stride(2), hn * s,
+                                              None, _sp()), "transpose")
+    return out
+
+
+def cast_bf16(src_f32):
+    dst = torch.empty(src_f32.shape, dtype=BF16, device=src_f32.device)
+    _native.check(_lib().emdr2_cast_f32_to_bf16(src_f32.data_ptr(), dst.data_ptr(), src_f32.numel(), _sp()), "cast")
+    return dst
+
+
+class _WeightCache(object):
+    """bf16 working copies of the fp32 master parameters (and their transposes), refreshed when the master changes."""
+
+    def __init__(self):
+        self.store = {}
+
+    def get(self, p, kind, build):
+        key = (p.data_ptr(), kind)
+        ent = self.store.get(key)
+        if ent is None or ent[0] != p._version:
+            ent = (p._version, build())
+            self.store[key] = ent
+        return ent[1]
+
+
+WEIGHTS = _WeightCache()
+
+
+def w_bf16(p):
+    return WEIGHTS.get(p, "bf16", lambda: cast_bf16(p.detach().contiguous()))
+
+
+def w_bf16_t(p):
+    return WEIGHTS.get(p, "bf16_t", lambda: transpose(w_bf16(p)))
+
+
+def w_bf16_perm(p, perm):
+    """bf16 copy with rows gathered as perm (de-interleaving the reference's [np, hn, 3] QKV row order once per weight update)."""
+    return WEIGHTS.get(p, "perm", lambda: w_bf16(p)[perm].contiguous())
+
+
+def _accum_grad(p, g_f32):
+    if p.grad is None:
+        p.grad = g_f32
+    else:
+        p.grad += g_f32        # rare (a parameter used twice in one backward): tied embedding / LM head
+
+
+# ---- autograd functions ----------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b, optional exact-erf GELU, optional residual add (the reference's F.linear + bias(+gelu) / bias-dropout-add at
+    p = 0: mpu/layers.py:255,353, transformer.py:94-108,397-407).  W, b are fp32 masters; GEMMs run on bf16 copies."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gelu, residual, row_perm=None):
+        _check_bf16(x, residual)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            raise ValueError("linear input must be contiguous")
+        M, K = x2.shape
+        N = weight.shape[0]
+        y = torch.empty((M, N), dtype=BF16, device=x.device)
+        pre = torch.empty_like(y) if gelu else None
+        res2 = residual.reshape(M, N) if residual is not None else None
+        wb = w_bf16(weight) if row_perm is None else w_bf16_perm(weight, row_perm)
+        bb = None
+        if bias is not None:
+            bb = bias.detach() if row_perm is None else WEIGHTS.get(bias, "perm", lambda: bias.detach()[row_perm].contiguous())
+        gemm_nt(x2, K, wb, K, y, N, M, N, K, bias=bb, gelu=gelu, pre_act=pre, residual=res2)
+        ctx.save_for_backward(x2, pre)
+        ctx.weight, ctx.bias, ctx.gelu, ctx.has_res, ctx.shp, ctx.row_perm = weight, bias, gelu, residual is not None, shp, row_perm
+        return y.reshape(shp[:-1] + (N,))
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre = ctx.saved_tensors
+        weight, bias = ctx.weight, ctx.bias
+        M, K = x2.shape
+        N = weight.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy if ctx.has_res else None
+        if ctx.gelu:
+            dpre = torch.empty_like(dy2)
+            _native.check(_lib().emdr2_gelu_bwd(pre.data_ptr(), dy2.data_ptr(), dpre.data_ptr(), dy2.numel(), _sp()), "gelu_bwd")
+            dy2 = dpre
+        dx = None
+        if ctx.needs_input_grad[0]:
+            wt = w_bf16_t(weight) if ctx.row_perm is None else WEIGHTS.get(weight, "perm_t", lambda: transpose(w_bf16_perm(weight, ctx.row_perm)))
+            dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                      # [M,N] x [K,N]^T
+        if weight.requires_grad:
+            db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias is not None else None
+            dyT = transpose(dy2, colsum=db)                                               # [N, M] (+ bias gradient)
+            xT = transpose(x2)                                                            # [K, M]
+            if M % 32:
+                raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
+            dW = matmul_nt(dyT, xT, out_dtype=torch.float32)                              # [N, K] fp32
+            if ctx.row_perm is not None:                                                  # back to the checkpoint's interleaved row order
+                un = torch.empty_like(dW); un[ctx.row_perm] = dW; dW = un
+                if bias is not None:
+                    ub = torch.empty_like(db); ub[ctx.row_perm] = db; db = ub
+            _accum_grad(weight, dW)
+            if bias is not None:
+                _accum_grad(bias, db)
+        return dx, None, None, None, dres, None
+
+
+def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None):
+    return LinearFn.apply(x, weight, bias, gelu, residual, row_perm)
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _check_bf16(x)
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H)
+        rows = x2.shape[0]
+        y = torch.empty_like(x2)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        _native.check(_lib().emdr2_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                                 rows, H, eps, _sp()), "layernorm_fwd")
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.gamma, ctx.beta = gamma, beta
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.gamma, ctx.beta
+        rows, H = x2.shape
+        dy2 = dy.reshape(rows, H).contiguous()
+        dx = torch.empty_like(x2)
+        dg = torch.zeros(H, dtype=torch.float32, device=dy.device)
+        db = torch.zeros_like(dg)
+        _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
+        _accum_grad(gamma, dg)
+        _accum_grad(beta, db)
+        return dx.reshape(dy.shape), None, None, None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """softmax(mask(Q K^T / sqrt(hn))) V for all heads (transformer.py:283-381).  q [b, sq, np, hn], k, v [b, sk, np, hn] are strided
+    views (last dim contiguous) into the projection outputs; masks come from token ids (pad id 0) + optional history mask."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, ids_q, ids_k, causal):
+        _check_bf16(q, k, v)
+        b, sq, heads, hn = q.shape
+        sk = k.shape[1]
+        dev = q.device
+        scale = 1.0 / math.sqrt(hn)
+        S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
+        gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
+                sq * sk, alpha=scale)
+        m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
+        l = torch.empty_like(m)
+        _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal), m.data_ptr(),
+                                                    l.data_ptr(), _sp()), "softmax_fwd")
+        vT = head_transpose(v, b, sk, heads, hn)
+        ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
+        gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
+        ctx.save_for_backward(q, k, v, S, m, l, ids_q, ids_k)
+        ctx.causal = causal
+        return ctxo
+
+    @staticmethod
+    def backward(ctx, dctx):
+        q, k, v, P, m, l, ids_q, ids_k = ctx.saved_tensors
+        b, sq, heads, hn = q.shape
+        sk = k.shape[1]
+        dev = q.device
+        causal = int(ctx.causal)
+        scale = 1.0 / math.sqrt(hn)
+        dctx = dctx.contiguous()
+        H = heads * hn
+        lib = _lib()
+        # dP = dctx V^T, dS = P (dP - D)
+        dP = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
+        gemm_nt(dctx, H, v, v.stride(1), dP, sk, sq, sk, hn, b, sq * H, v.stride(0), heads * sq * sk, heads, hn, v.stride(2), sq * sk)
+        D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
+        _native.check(lib.emdr2_softmax_mask_bwd(P.data_ptr(), dP.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, causal,
+                                                 D.data_ptr(), _sp()), "softmax_bwd")
+        dq = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
+        kT = head_transpose(k, b, sk, heads, hn)
+        gemm_nt(dP, sk, kT, sk, dq, H, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * H, heads, sq * sk, hn * sk, hn, alpha=scale)
+        # transposed branch: S^T, dP^T recomputed in the orientation dK / dV need (no [sq, sk] transposes)
+        St = torch.empty((b, heads, sk, sq), dtype=BF16, device=dev)
+        gemm_nt(k, k.stride(1), q, q.stride(1), St, sq, sk, sq, hn, b, k.stride(0), q.stride(0), heads * sk * sq, heads, k.stride(2), q.stride(2),
+                sk * sq, alpha=scale)
+        dPt = torch.empty_like(St)
+        gemm_nt(v, v.stride(1), dctx, H, dPt, sq, sk, sq, hn, b, v.stride(0), sq * H, heads * sk * sq, heads, v.stride(2), hn, sk * sq)
+        _native.check(lib.emdr2_softmax_mask_t(St.data_ptr(), dPt.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(),
+                                               D.data_ptr(), b, heads, sq, sk, causal, _sp()), "softmax_t")
+        qT = head_transpose(q, b, sq, heads, hn)
+        dk = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
+        gemm_nt(dPt, sq, qT, sq, dk, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn, alpha=scale)
+        dctxT = head_transpose(dctx.view(b, sq, heads, hn), b, sq, heads, hn)
+        dv = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
+        gemm_nt(St, sq, dctxT, sq, dv, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn)
+        return dq, dk, dv, None, None, None
+
+
+def attention_core(q, k, v, ids_q, ids_k, causal=False):
+    return AttentionCoreFn.apply(q, k, v, ids_q, ids_k, causal)
+
+
+class EmbeddingFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ids, types, W, P, T):
+        b, s = ids.shape
+        H = W.shape[1]
+        out = torch.empty((b, s, H), dtype=BF16, device=ids.device)
+        ids = ids.contiguous()
+        types = types.contiguous() if types is not None else None
+        _native.check(_lib().emdr2_embedding_fwd(ids.data_ptr(), _ptr(types), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
+                                                 w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), b * s, s, H, _sp()), "embedding_fwd")
+        ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T = ids, types, W, P, T
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ids, types, W, P, T = ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T
+        b, s = ids.shape
+        H = W.shape[1]
+        dout = dout.contiguous()
+        dW, dP = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(P, dtype=torch.float32)
+        dT = torch.zeros_like(T, dtype=torch.float32) if types is not None else None
+        _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
+                                                 _sp()), "embedding_bwd")
+        _accum_grad(W, dW)
+        _accum_grad(P, dP)
+        if dT is not None:
+            _accum_grad(T, dT)
+        return None, None, None, None, None
+
+
+def embedding(ids, types, W, P, T):
+    return EmbeddingFn.apply(ids, types, W, P, T)
+
+
+class LseGatherFn(torch.autograd.Function):
+    """gold[row] = log_softmax(logits[row])[label[row]] over the vocabulary (fp32 out)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        _check_bf16(logits)
+        V = logits.shape[-1]
+        l2 = logits.reshape(-1, V)
+        lab = labels.reshape(-1).contiguous()
+        rows = l2.shape[0]
+        gold = torch.empty(rows, dtype=torch.float32, device=logits.device)
+        lse = torch.empty_like(gold)
+        _native.check(_lib().emdr2_lse_gather_fwd(l2.data_ptr(), lab.data_ptr(), gold.data_ptr(), lse.data_ptr(), rows, V, _sp()), "lse_gather_fwd")
+        ctx.save_for_backward(l2, lab, lse)
+        ctx.shape = logits.shape
+        return gold.reshape(labels.shape)
+
+    @staticmethod
+    def backward(ctx, dgold):
+        l2, lab, lse = ctx.saved_tensors
+        rows, V = l2.shape
+        w = dgold.reshape(-1).to(torch.float32).contiguous()
+        dl = torch.empty_like(l2)
+        _native.check(_lib().emdr2_lse_gather_bwd(l2.data_ptr(), lab.data_ptr(), lse.data_ptr(), w.data_ptr(), dl.data_ptr(), rows, V, _sp()),
+                      "lse_gather_bwd")
+        return dl.reshape(ctx.shape), None
+
+
+def lse_gather(logits, labels):
+    return LseGatherFn.apply(logits, labels)

@@ -1,0 +1,223 @@
+"""Encoder / reader modules of the EMDR2 hot path on the HIP kernels of include/emdr2_ops.h, with the reference's module
+tree and parameter names so its checkpoints load unchanged (`state_dict` keys identical to the reference's):
+
+  ParallelMLP, ParallelAttention, ParallelTransformerLayer, ParallelTransformer   megatron/model/transformer.py:58-699
+  Embedding, TransformerLanguageModel                                             megatron/model/language_model.py:98-358
+  PretrainedBertModel, DualEncoderModel                                           megatron/model/dualencoder_model.py:40-194
+  T5LMHead, T5Model                                                               megatron/model/t5_model.py:54-154
+
+Differences that are deliberate: activations are [b, s, h] bf16 (the reference: [s, b, h] fp16); parameters are fp32 masters whose
+bf16 working copies are refreshed after each optimizer step; attention masks are not materialised (the kernels derive them from token
+ids: pad id 0, plus the history mask for decoder self-attention) - `forward` therefore takes token ids where the reference takes masks;
+tensor model parallelism is not built (asserted 1 in the reference, dualencoder_model.py:15).  Dropout probabilities must be 0 in this
+round (the reference's parity configuration); see DESIGN.md.
+"""
+import math
+
+import torch
+
+from emdr2_amd.model import kernels as K
+
+
+def _normal(shape, std, gen=None):
+    return torch.nn.Parameter(torch.empty(shape, dtype=torch.float32, device="cuda").normal_(0.0, std, generator=gen))
+
+
+class Config(object):
+    """The architecture flags of megatron/arguments.py that the hot path reads."""
+
+    def __init__(self, num_layers=12, hidden_size=768, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512,
+                 layernorm_epsilon=1e-5, init_method_std=0.02, hidden_dropout=0.0, attention_dropout=0.0):
+        if hidden_dropout or attention_dropout:
+            raise NotImplementedError("dropout > 0 is not built yet (parity runs use 0, SURVEY.md section 7)")
+        self.num_layers, self.hidden_size, self.num_attention_heads = num_layers, hidden_size, num_attention_heads
+        self.ffn_hidden_size, self.max_position_embeddings = ffn_hidden_size, max_position_embeddings
+        self.layernorm_epsilon, self.init_method_std = layernorm_epsilon, init_method_std
+        self.kv_channels = hidden_size // num_attention_heads
+
+
+class Linear(torch.nn.Module):
+    def __init__(self, n_in, n_out, std):
+        super().__init__()
+        self.weight = _normal((n_out, n_in), std)
+        self.bias = torch.nn.Parameter(torch.zeros(n_out, dtype=torch.float32, device="cuda"))
+
+
+class LayerNorm(torch.nn.Module):
+    def __init__(self, h, eps):
+        super().__init__()
+        self.weight = torch.nn.Parameter(torch.ones(h, dtype=torch.float32, device="cuda"))
+        self.bias = torch.nn.Parameter(torch.zeros(h, dtype=torch.float32, device="cuda"))
+        self.eps = eps
+
+    def forward(self, x):
+        return K.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+def _deinterleave_perm(heads, hn, parts, device):
+    """row r' = t*h + n*hn + d of the de-interleaved weight  <-  row n*hn*parts + d*parts + t of the checkpoint layout
+    (transformer.py:231-240: the projection output is viewed as [..., np, hn, 3])."""
+    t, n, d = torch.meshgrid(torch.arange(parts), torch.arange(heads), torch.arange(hn), indexing="ij")
+    return (n * hn * parts + d * parts + t).reshape(-1).to(device)
+
+
+class ParallelMLP(torch.nn.Module):
+    def __init__(self, cfg, out_std):
+        super().__init__()
+        self.dense_h_to_4h = Linear(cfg.hidden_size, cfg.ffn_hidden_size, cfg.init_method_std)
+        self.dense_4h_to_h = Linear(cfg.ffn_hidden_size, cfg.hidden_size, out_std)
+
+    def forward(self, x, residual):
+        inter = K.linear(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, gelu=True)          # bias + exact-erf GELU in the epilogue
+        return K.linear(inter, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, residual=residual)  # bias + residual in the epilogue
+
+
+class ParallelAttention(torch.nn.Module):
+    def __init__(self, cfg, out_std, attention_type="self"):
+        super().__init__()
+        h = cfg.hidden_size
+        self.heads, self.hn, self.attention_type = cfg.num_attention_heads, cfg.kv_channels, attention_type
+        if attention_type == "self":
+            self.query_key_value = Linear(h, 3 * h, cfg.init_method_std)
+            self.register_buffer("_perm", _deinterleave_perm(self.heads, self.hn, 3, "cuda"), persistent=False)
+        else:
+            self.query = Linear(h, h, cfg.init_method_std)
+            self.key_value = Linear(h, 2 * h, cfg.init_method_std)
+            self.register_buffer("_perm", _deinterleave_perm(self.heads, self.hn, 2, "cuda"), persistent=False)
+        self.dense = Linear(h, h, out_std)
+
+    def forward(self, x, ids_q, ids_k, causal, residual, encoder_output=None):
+        b, sq, h = x.shape
+        if self.attention_type == "self":
+            mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(b, sq, 3, self.heads, self.hn)
+            q, k, v = mixed[:, :, 0], mixed[:, :, 1], mixed[:, :, 2]
+        else:
+            sk = encoder_output.shape[1]
+            kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
+            k, v = kv[:, :, 0], kv[:, :, 1]
+            q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
+        ctx = K.attention_core(q, k, v, ids_q, ids_k, causal).view(b, sq, h)
+        return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual)
+
+
+class ParallelTransformerLayer(torch.nn.Module):
+    def __init__(self, cfg, out_std, layer_type="encoder"):
+        super().__init__()
+        self.layer_type = layer_type
+        self.input_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
+        self.self_attention = ParallelAttention(cfg, out_std, "self")
+        self.post_attention_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
+        if layer_type == "decoder":
+            self.inter_attention = ParallelAttention(cfg, out_std, "cross")
+            self.post_inter_attention_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
+        self.mlp = ParallelMLP(cfg, out_std)
+
+    def forward(self, x, ids, causal, encoder_output=None, enc_ids=None):
+        x = self.self_attention(self.input_layernorm(x), ids, ids, causal, residual=x)
+        ln = self.post_attention_layernorm(x)
+        if self.layer_type == "decoder":
+            x = self.inter_attention(ln, ids, enc_ids, False, residual=x, encoder_output=encoder_output)
+            ln = self.post_inter_attention_layernorm(x)
+        return self.mlp(ln, residual=x)
+
+
+class ParallelTransformer(torch.nn.Module):
+    def __init__(self, cfg, layer_type="encoder", checkpoint_activations=False):
+        super().__init__()
+        out_std = cfg.init_method_std / math.sqrt(2.0 * cfg.num_layers)                   # scaled_init_method_normal (model/utils.py)
+        self.layers = torch.nn.ModuleList([ParallelTransformerLayer(cfg, out_std, layer_type) for _ in range(cfg.num_layers)])
+        self.final_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
+        self.checkpoint_activations = checkpoint_activations
+
+    def forward(self, x, ids, causal=False, encoder_output=None, enc_ids=None):
+        for layer in self.layers:
+            if self.checkpoint_activations and torch.is_grad_enabled():
+                x = torch.utils.checkpoint.checkpoint(layer, x, ids, causal, encoder_output, enc_ids, use_reentrant=False)
+            else:
+                x = layer(x, ids, causal, encoder_output, enc_ids)
+        return self.final_layernorm(x)
+
+
+class _Table(torch.nn.Module):
+    def __init__(self, n, h, std):
+        super().__init__()
+        self.weight = _normal((n, h), std)
+
+
+class Embedding(torch.nn.Module):
+    def __init__(self, cfg, vocab_size, num_tokentypes):
+        super().__init__()
+        self.word_embeddings = _Table(vocab_size, cfg.hidden_size, cfg.init_method_std)
+        self.position_embeddings = _Table(cfg.max_position_embeddings, cfg.hidden_size, cfg.init_method_std)
+        self.tokentype_embeddings = _Table(num_tokentypes, cfg.hidden_size, cfg.init_method_std) if num_tokentypes > 0 else None
+
+    def forward(self, ids, tokentype_ids=None):
+        T = self.tokentype_embeddings.weight if tokentype_ids is not None else None
+        return K.embedding(ids, tokentype_ids, self.word_embeddings.weight, self.position_embeddings.weight, T)
+
+
+class TransformerLanguageModel(torch.nn.Module):
+    def __init__(self, cfg, vocab_size, num_tokentypes=0, add_decoder=False, checkpoint_activations=False):
+        super().__init__()
+        self.embedding = Embedding(cfg, vocab_size, num_tokentypes)
+        self.encoder = ParallelTransformer(cfg, "encoder", checkpoint_activations)
+        self.add_decoder = add_decoder
+        if add_decoder:
+            self.decoder = ParallelTransformer(cfg, "decoder", checkpoint_activations)
+
+    def encode(self, enc_ids, tokentype_ids=None):
+        return self.encoder(self.embedding(enc_ids, tokentype_ids), enc_ids)
+
+    def decode(self, dec_ids, encoder_output, enc_ids):
+        return self.decoder(self.embedding(dec_ids), dec_ids, causal=True, encoder_output=encoder_output, enc_ids=enc_ids)
+
+
+class PretrainedBertModel(torch.nn.Module):
+    """BERT tower -> hidden state of token 0 (no pooler; dualencoder_model.py:166-181)."""
+
+    def __init__(self, cfg, vocab_size, num_tokentypes=2, checkpoint_activations=False):
+        super().__init__()
+        self.language_model = TransformerLanguageModel(cfg, vocab_size, num_tokentypes, False, checkpoint_activations)
+
+    def forward(self, input_ids, tokentype_ids=None):
+        return self.language_model.encode(input_ids, tokentype_ids)[:, 0, :]
+
+
+class DualEncoderModel(torch.nn.Module):
+    def __init__(self, cfg, vocab_size, checkpoint_activations=False):
+        super().__init__()
+        self.query_model = PretrainedBertModel(cfg, vocab_size, 2, checkpoint_activations)
+        self.context_model = PretrainedBertModel(cfg, vocab_size, 2, checkpoint_activations)
+
+    @staticmethod
+    def embed_text(model, tokens, types):
+        return model(tokens, types)
+
+
+class T5LMHead(torch.nn.Module):
+    def __init__(self, vocab_size):
+        super().__init__()
+        self.bias = torch.nn.Parameter(torch.zeros(vocab_size, dtype=torch.float32, device="cuda"))
+
+    def forward(self, hidden, word_embeddings_weight):
+        return K.linear(hidden, word_embeddings_weight, self.bias)                        # tied LM head (language_model.py:28-41)
+
+
+class T5Model(torch.nn.Module):
+    """Megatron-style encoder-decoder reader (t5_model.py:84-154): learned absolute positions, pre-LN, GELU, tied LM head + bias."""
+
+    def __init__(self, cfg, vocab_size, num_tokentypes=2, checkpoint_activations=False):
+        super().__init__()
+        self.language_model = TransformerLanguageModel(cfg, vocab_size, num_tokentypes, True, checkpoint_activations)
+        self.lm_head = T5LMHead(vocab_size)
+
+    def encode(self, encoder_input_ids):
+        return self.language_model.encode(encoder_input_ids)
+
+    def decode(self, decoder_input_ids, enc_hidden_states, enc_ids):
+        dec = self.language_model.decode(decoder_input_ids, enc_hidden_states, enc_ids)
+        return self.lm_head(dec, self.language_model.embedding.word_embeddings.weight)
+
+    def forward(self, encoder_input_ids, decoder_input_ids):
+        enc = self.encode(encoder_input_ids)
+        return self.decode(decoder_input_ids, enc, encoder_input_ids), enc

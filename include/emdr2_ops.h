@@ -1,0 +1,79 @@
+/*
+ * include/emdr2_ops.h -- C ABI of the transformer-block kernels (libemdr2_hip.so): what the encoder / reader
+ * forward + backward of the EMDR2 hot path are made of.
+ *
+ * The reference runs these through torch / cuBLAS / apex from Python; the entry points below are what a binding
+ * next to megatron/model/transformer.py would call.  Each comment names the reference code it replaces.
+ * Conventions as in emdr2_mips.h: device pointers, element strides, int status (0 ok), enqueue on `stream`.
+ * Activations and weights are bf16 (round-to-nearest-even), accumulation and statistics fp32.
+ */
+#ifndef EMDR2_OPS_H
+#define EMDR2_OPS_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * C[b1,b2][m,n] = epi( alpha * sum_k A[b1,b2][m,k] * B[b1,b2][n,k] ),  epi = (+bias[n]) -> (GELU) -> (+residual[m,n])
+ * Replaces F.linear (mpu/layers.py:255,353), baddbmm/bmm (transformer.py:309-312,371), bias+GELU
+ * (transformer.py:103-104; exact erf), bias-dropout-add at p = 0 (transformer.py:397-407).
+ * K % 32 == 0; lda, ldb and the A/B batch strides multiples of 8 elements; A, B 16-byte aligned.
+ * pre_act (optional, bf16, indexed like C): value before GELU, kept for the backward.
+ */
+int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
+                       int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
+                       float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
+                       void *stream);
+
+/* out[b1,b2][c, r] = in[b1,b2][r, c] (bf16), optional fp32 column sums colsum[c] += sum_r in[r, c] over all batches
+ * (bias gradients: the reduce of the reference's autograd over [s, b]). */
+int emdr2_transpose_bf16(const void *in, int64_t ld_in, void *out, int64_t ld_out, int rows, int cols,
+                         int batch1, int64_t sI1, int64_t sO1, int batch2, int64_t sI2, int64_t sO2, float *colsum,
+                         void *stream);
+
+/* LayerNorm over the last dim (torch.nn.LayerNorm / apex FusedLayerNorm, mpu/layers.py:28-36; eps 1e-5, arguments.py:199).
+ * x, y bf16 [rows, H]; gamma, beta, mean, rstd fp32.  bwd: dx (+ dres, the residual-branch gradient, optional), dgamma / dbeta
+ * ACCUMULATED into fp32 buffers. */
+int emdr2_layernorm_fwd(const void *x, const float *gamma, const float *beta, void *y, float *mean, float *rstd, int64_t rows, int H,
+                        float eps, void *stream);
+int emdr2_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres, void *dx,
+                        float *dgamma, float *dbeta, int64_t rows, int H, void *stream);
+
+/* Scale-mask-softmax, the path the shipped scripts run (fused_softmax.py:113-125): masked scores are REPLACED by -10000
+ * (bert/t5_attention_mask_func), masks derived on the fly from token ids (pad id 0; mask_creation_utils.py:17-42),
+ * `causal` adds the history mask.  scores bf16 [batch, heads, sq, sk] in place; m, l: row max / sum-exp (fp32 [batch, heads, sq]).
+ * _bwd: dprobs -> dscores in place, d = rowsum(P*dP).  _t: transposed twin for the attention backward (see elementwise.hip). */
+int emdr2_softmax_mask_fwd(void *scores, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int causal,
+                           float *m, float *l, void *stream);
+int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
+                           int causal, float *d, void *stream);
+int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l,
+                         const float *d, int batch, int heads, int sq, int sk, int causal, void *stream);
+
+/* dpre = dact * gelu'(pre), exact-erf GELU (transformer.py:80,103-104; the tanh fusion of fused_bias_gelu.py is off in all scripts) */
+int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int64_t n, void *stream);
+
+/* Embedding.forward (language_model.py:169-181): out[t] = W[ids[t]] + P[t % S] (+ T[types[t]]); bwd scatter-adds into fp32 grads */
+int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, const void *W, const void *P, const void *T, void *out, int64_t tokens, int S,
+                        int H, void *stream);
+int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S, int H,
+                        void *stream);
+
+/* log-softmax over the vocabulary + gather of the gold token (train_e2eqa.py:79-96,152-160): gold[row] = logits[row, label] - lse */
+int emdr2_lse_gather_fwd(const void *logits, const int64_t *labels, float *gold, float *lse, int64_t rows, int V, void *stream);
+int emdr2_lse_gather_bwd(const void *logits, const int64_t *labels, const float *lse, const float *w, void *dlogits, int64_t rows, int V,
+                         void *stream);
+
+/* Optimizer step on fp32 masters (FP16_Optimizer + apex FusedAdam, training.py:89-93, fp16/fp16.py:420-474): global-norm clip
+ * (mpu/grads.py:74-127) folded in through gnorm_sq; decoupled weight decay; writes the bf16 working copy. */
+int emdr2_sumsq_f32(const float *g, int64_t n, float *out, void *stream);
+int emdr2_adam_step(float *master, const float *grad, float *m, float *v, void *param_bf16, int64_t n, float lr, float beta1, float beta2,
+                    float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream);
+int emdr2_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
+int emdr2_accum_bf16_to_f32(const void *src, float *dst, int64_t n, float scale, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
