@@ -90,3 +90,94 @@ class PreComputedEvidenceDocsRetriever(object):
         out = self.arena.assemble(topkindex, self.args.topk_retrievals, query_uid, query_ids_t5, query_ids_t5_len,
                                   self.args.seq_length_ret, self.args.seq_length, cls_id, sep_id, pad_id)
         return out + (distance,)
+
+
+# =====================================================================================================================
+# EMDR2Model: retriever towers + MIPS + reader, and the EMDR2 objective
+# =====================================================================================================================
+import math  # noqa: E402
+
+from emdr2_amd.model import kernels as K  # noqa: E402
+from emdr2_amd.model.transformer import Config, DualEncoderModel, T5Model  # noqa: E402
+
+
+class EMDR2Model(torch.nn.Module):
+    """reference: megatron/model/emdr2_model.py:31-247.  Same sub-module names (`language_model`, `retriever_model`), same
+    checkpoint keys ('encoder/t5_model', 'retriever/biencoder_model'), same training-mode return triple
+    (lm_logits [B,L,V], topk_log_probs [B,K], lm_logits_one_context [B,K,L,V]).  Masks are derived from token ids inside the
+    kernels, so `query_mask_bert` is accepted for signature compatibility and ignored."""
+
+    def __init__(self, evidence_retriever, cfg, t5_vocab_size, bert_vocab_size, topk, seq_length, seq_length_ret, cls_id, sep_id, pad_id=0,
+                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False):
+        super().__init__()
+        self.topk = topk
+        self.language_model = T5Model(cfg, t5_vocab_size, 2, checkpoint_activations)
+        self._language_model_key = 'encoder/t5_model'
+        self.retriever_model = DualEncoderModel(cfg, bert_vocab_size, checkpoint_activations)
+        self._retriever_model_key = 'retriever/biencoder_model'
+        self.evidence_retriever = evidence_retriever
+        self.hidden_size = cfg.hidden_size
+        self.seq_length, self.seq_length_ret = seq_length, seq_length_ret
+        self.cls_id, self.sep_id, self.pad_id = cls_id, sep_id, pad_id
+        self.update_retriever, self.retriever_score_scaling = update_retriever, retriever_score_scaling
+
+    def retriever_embedder(self, tokens, mask, types, embedder_type, disable_dropout=False):
+        tower = self.retriever_model.query_model if embedder_type == "query" else self.retriever_model.context_model
+        return self.retriever_model.embed_text(tower, tokens, types)
+
+    def forward(self, query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5, query_ids_t5_len, dec_ids):
+        query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query")
+        with torch.no_grad():                                            # emdr2_model.py:107-115 on the device
+            ctx_ids, ctx_types, qext, qone, _, _ = self.evidence_retriever.get_topk_assembled(
+                query_logits.detach(), query_uid, query_ids_t5, query_ids_t5_len, self.cls_id, self.sep_id, self.pad_id)
+        return self.forward_assembled(query_logits, ctx_ids, ctx_types, qext, qone, dec_ids)
+
+    def forward_assembled(self, query_logits, ctx_ids, ctx_types, qext, qone, dec_ids):
+        B, Kk = ctx_ids.shape[:2]
+        H = self.hidden_size
+        ctx_logits = self.retriever_embedder(ctx_ids.reshape(B * Kk, -1), None, ctx_types.reshape(B * Kk, -1), "context").reshape(B, Kk, H)
+        # fresh retriever scores (emdr2_model.py:134-145): 2*B*K*H flop, negligible; kept in torch fp32 on purpose
+        sim = torch.bmm(query_logits.unsqueeze(1).float(), ctx_logits.float().transpose(1, 2))
+        if self.retriever_score_scaling:
+            sim = sim / math.sqrt(H)
+        topk_log_probs = torch.log_softmax(sim, dim=2).squeeze(1)
+
+        S = qext.shape[1]
+        enc = self.language_model.encode(qext).reshape(B, Kk * S, H)                          # K passages concatenated (FiD), :148-164
+        lm_logits = self.language_model.decode(dec_ids, enc, qext.reshape(B, Kk * S))           # :166-183
+
+        one = None
+        if self.training and self.update_retriever:
+            with torch.no_grad():                                                             # :185-210
+                dec_rep = torch.repeat_interleave(dec_ids, Kk, dim=0)
+                enc1 = self.language_model.encode(qone)
+                one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
+        return lm_logits, topk_log_probs, one
+
+    def state_dict_for_save_checkpoint(self):
+        return {self._language_model_key: self.language_model.state_dict(), self._retriever_model_key: self.retriever_model.state_dict()}
+
+    def load_state_dict_from_checkpoint(self, state):
+        self.language_model.load_state_dict(state[self._language_model_key])
+        self.retriever_model.load_state_dict(state[self._retriever_model_key])
+
+
+def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id):
+    """_cross_entropy_forward_step + get_loss_and_retriever_utility (tasks/openqa/e2eqa/train_e2eqa.py:72-181).
+    The two vocabulary-sized log-softmax + gather passes run in the HIP kernel; what is left in torch acts on [B,L] / [B,K,L]."""
+    mask = loss_mask.float()
+    gold = K.lse_gather(lm_logits, labels)                                                    # [B, L] fp32
+    lm_loss = -torch.sum(gold * mask * (labels != 0)) / mask.sum()                            # CrossEntropyLoss(ignore_index=0) * loss_mask
+    stats = {"lm_loss": lm_loss.detach()}
+    retriever_loss = torch.zeros((), device=lm_logits.device)
+    if lm_logits_one_context is not None:
+        Kk = lm_logits_one_context.shape[1]
+        lab = labels.masked_fill(~loss_mask.to(torch.bool), 0)
+        gold1 = K.lse_gather(lm_logits_one_context, lab.unsqueeze(1).expand(-1, Kk, -1).contiguous()).detach()   # [B, K, L]
+        marginal = torch.logsumexp(topk_log_probs.float().unsqueeze(-1) + gold1, dim=1)
+        retriever_loss = -torch.sum(marginal * mask) / mask.sum()
+        util_mask = mask.masked_fill(lab >= eos_id, 0)
+        stats["retriever_utility"] = (torch.sum((marginal - gold1[:, -1, :]) * util_mask) / util_mask.sum()).detach()
+        stats["null_block_lm_loss"] = (-torch.sum(gold1[:, -1, :] * mask) / mask.sum()).detach()
+    stats["retriever_loss"] = retriever_loss.detach()
+    return lm_loss + retriever_loss, stats

@@ -69,18 +69,24 @@ def cast_bf16(src_f32):
 
 
 class _WeightCache(object):
-    """bf16 working copies of the fp32 master parameters (and their transposes), refreshed when the master changes."""
+    """bf16 working copies of the fp32 master parameters (plus transposed / row-permuted forms), kept ON the parameter object and
+    rebuilt when the master changed: either its autograd version moved (in-place torch update) or the optimizer bumped `epoch`
+    (the HIP Adam kernel writes the master through a raw pointer, which autograd cannot see)."""
 
     def __init__(self):
-        self.store = {}
+        self.epoch = 0
 
     def get(self, p, kind, build):
-        key = (p.data_ptr(), kind)
-        ent = self.store.get(key)
-        if ent is None or ent[0] != p._version:
-            ent = (p._version, build())
-            self.store[key] = ent
+        cache = p.__dict__.setdefault("_emdr2_cache", {})
+        ent = cache.get(kind)
+        stamp = (p._version, self.epoch)
+        if ent is None or ent[0] != stamp:
+            ent = (stamp, build())
+            cache[kind] = ent
         return ent[1]
+
+    def invalidate(self):
+        self.epoch += 1
 
 
 WEIGHTS = _WeightCache()

@@ -98,3 +98,62 @@ def test_state_dict_keys_match_reference_fixture():
     ours = {"language_model." + k: tuple(v.shape) for k, v in t5.state_dict().items()}
     ours.update({"retriever_model." + k: tuple(v.shape) for k, v in de.state_dict().items()})
     assert ours == {k: tuple(v.shape) for k, v in P.items()}
+
+
+def test_emdr2_forward_loss_and_gradients_vs_oracle():
+    """Row a9-a14: EMDR2Model.forward (training, update_retriever) + the EMDR2 objective + backward, on assembled inputs."""
+    from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
+    rng = np.random.default_rng(7)
+    B, Kk, S_ret, S, L, V = 4, 8, 32, 64, 32, 640
+    torch.manual_seed(0)
+    m = EMDR2Model(None, _cfg(), V, 512, Kk, S, S_ret, cls_id=2, sep_id=3)
+    _perturb(m, 5)
+    m.train()
+    qb = _ids(rng, (B, S_ret), 512); ctx = _ids(rng, (B, Kk, S_ret), 512); typ = torch.zeros_like(ctx)
+    qext, qone = _ids(rng, (B * Kk, S), 600), _ids(rng, (B * Kk, S), 600)
+    dec = _ids(rng, (B, L), 600)
+    labels = torch.roll(dec, -1, 1); labels[:, -1] = 0
+    loss_mask = (labels != 0).float()
+    q_logits = m.retriever_embedder(qb.cuda(), None, torch.zeros_like(qb).cuda(), "query")
+    lm, tlp, one = m.forward_assembled(q_logits, ctx.cuda(), typ.cuda(), qext.cuda(), qone.cuda(), dec.cuda())
+    loss, stats = emdr2_loss(lm, tlp, one, labels.cuda(), loss_mask.cuda(), eos_id=601)
+    loss.backward()
+
+    P = {k: v.requires_grad_(True) for k, v in _params_cpu(m).items()}
+    lm_r, tlp_r, one_r = to.emdr2_forward(P, CFG, qb, torch.zeros_like(qb), ~to.make_attention_mask_3d(qb, qb), ctx, typ, qext, qone, dec)
+    lm_loss_r = to.reader_ce_loss(lm_r, labels, loss_mask)
+    r_loss_r, util_r, null_r = to.retriever_loss_and_utility(one_r, tlp_r, labels, loss_mask, 601)
+    (lm_loss_r + r_loss_r).backward()
+    assert _rel(lm.float().cpu(), lm_r) < 2e-2 and _rel(one.float().cpu(), one_r) < 2e-2
+    assert float((tlp.detach().cpu() - tlp_r.detach()).abs().max()) < 2e-2
+    assert abs(float(stats["lm_loss"]) - float(lm_loss_r)) < 2e-2 * float(lm_loss_r)
+    assert abs(float(stats["retriever_loss"]) - float(r_loss_r)) < 2e-2 * float(r_loss_r)
+    bad = []
+    gmax = max(float(P[k].grad.abs().max()) for k in P if P[k].grad is not None)
+    for k, p in m.named_parameters():
+        g_ref = P[k].grad
+        if g_ref is None:
+            continue
+        # gradients that are analytically zero (e.g. the context tower's last LN bias: a common shift of all K context embeddings
+        # leaves log_softmax over K unchanged) are compared on the scale of the whole gradient, not their own round-off
+        r = float((p.grad.cpu() - g_ref).abs().max() / max(float(g_ref.abs().max()), 1e-2 * gmax))
+        if r > 8e-2:
+            bad.append((k, r))
+    assert not bad, bad[:5]
+
+
+def test_adam_step_matches_torch_adamw_with_clipping():
+    from emdr2_amd.training import FusedAdam
+    g = torch.Generator(device="cuda").manual_seed(3)
+    ps = [torch.nn.Parameter(torch.randn(s, generator=g, device="cuda")) for s in ((300, 70), (513,), (64, 64))]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    opt = FusedAdam([{"params": ps[:2]}, {"params": ps[2:], "weight_decay": 0.0}], lr=1e-2, weight_decay=0.1, clip_grad=1.0)
+    ropt = torch.optim.AdamW([{"params": ref[:2], "weight_decay": 0.1}, {"params": ref[2:], "weight_decay": 0.0}], lr=1e-2, betas=(0.9, 0.999), eps=1e-8)
+    for it in range(3):
+        for p, r in zip(ps, ref):
+            gr = torch.randn(p.shape, generator=g, device="cuda") * 3
+            p.grad, r.grad = gr.clone(), gr.clone()
+        torch.nn.utils.clip_grad_norm_(ref, 1.0)
+        ropt.step(); opt.step()
+    for p, r in zip(ps, ref):
+        assert torch.allclose(p, r, rtol=1e-5, atol=1e-6)
