@@ -30,6 +30,7 @@ struct GemmParams {
     int M, N, K, batch2;
     float alpha;
     int gelu, out_f32;
+    int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
@@ -57,7 +58,8 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     const int swz = (l31 >> 2) & 3;
 
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int b1 = blockIdx.z / p.batch2, b2 = blockIdx.z % p.batch2;
+    const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
+    const int b1 = zb / p.batch2, b2 = zb % p.batch2;
     const char *A = p.A + ((long long)b1 * p.sA1 + (long long)b2 * p.sA2) * 2;
     const char *B = p.B + ((long long)b1 * p.sB1 + (long long)b2 * p.sB2) * 2;
     const long long coff = (long long)b1 * p.sC1 + (long long)b2 * p.sC2;
@@ -87,10 +89,14 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
         b_src[j] = B + ((long long)gn * p.ldb + ((pslot ^ ((r >> 2) & 3)) << 3)) * 2;
     }
 
-    const int nch = p.K >> 5;
+    const int nch_all = p.K >> 5;
+    const int per = (nch_all + p.splitk - 1) / p.splitk;
+    const int c_begin = zs * per;
+    const int nch = (c_begin + per <= nch_all ? per : (nch_all > c_begin ? nch_all - c_begin : 0));
+    if (nch == 0) return;
     int pf_c = 0, pf_stage = 0;
     auto issue = [&]() {
-        const int c = pf_c < nch ? pf_c : nch - 1;                  // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
+        const int c = c_begin + (pf_c < nch ? pf_c : nch - 1);      // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
         char *sb = smem + pf_stage * STAGE;
 #pragma unroll
         for (int j = 0; j < A_PW; ++j)
@@ -156,7 +162,8 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
                 if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
                 if (p.gelu) v = gelu_erf(v);
                 if (p.R) v += bf16_to_f32(((const uint16_t *)p.R)[o]);
-                if (p.out_f32) ((float *)p.C)[o] = v;
+                if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
+                else if (p.out_f32) ((float *)p.C)[o] = v;
                 else ((uint16_t *)p.C)[o] = f32_to_bf16(v);
             }
         }
@@ -173,7 +180,7 @@ static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
         if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch);
+    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch * p.splitk);
     hipLaunchKernelGGL((gemm_nt_kernel<WM, WN>), grid, dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
@@ -181,9 +188,10 @@ static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
 extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
                                   int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
                                   float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
-                                  void *stream)
+                                  int split_k, void *stream)
 {
-    if (!A || !B || !C || M < 1 || N < 1 || K < 32 || (K & 31) || batch1 < 1 || batch2 < 1) return -1;
+    if (!A || !B || !C || M < 1 || N < 1 || K < 32 || (K & 31) || batch1 < 1 || batch2 < 1 || split_k < 1) return -1;
+    if (split_k > 1 && (!out_f32 || bias || gelu || pre_act || residual)) return -1;
     if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return -1;
     if ((sA1 & 7) || (sB1 & 7) || (sA2 & 7) || (sB2 & 7)) return -1;
     GemmParams p;
@@ -191,7 +199,7 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     p.bias = bias; p.R = (const char *)residual;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
-    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32;
+    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k;
     const int batch = batch1 * batch2;
     if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
     if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);

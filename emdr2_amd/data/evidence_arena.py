@@ -57,6 +57,40 @@ class EvidenceArena(object):
         self.dev = None
         self._struct = None
 
+    @classmethod
+    def synthetic(cls, n_docs, seed=1234, vocab=30522, device=None):
+        """Synthetic corpus built directly in HBM for benchmarks (passages U[100,160] tokens, titles U[2,8],
+        title groups of 1-10 consecutive ids).  No host copy: only `assemble` works on it."""
+        self = cls.__new__(cls)
+        dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        plen = torch.randint(100, 161, (n_docs,), generator=g, device=dev)
+        gsize = torch.randint(1, 11, (n_docs,), generator=g, device=dev)              # more than enough groups
+        gend = torch.cumsum(gsize, 0)
+        n_groups = int(torch.searchsorted(gend, torch.tensor([n_docs], device=dev)).item()) + 1
+        gend = torch.clamp(gend[:n_groups], max=n_docs)
+        g_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), gend])
+        doc = torch.arange(n_docs, device=dev)
+        doc_group = torch.searchsorted(gend, doc, right=True).to(torch.int32)
+        doc_pos = (doc - g_off[doc_group.long()]).to(torch.int32)
+        tlen_g = torch.randint(2, 9, (n_groups,), generator=g, device=dev)
+        tlen = tlen_g[doc_group.long()]
+        p_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(plen, 0)])
+        t_off = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(tlen, 0)])
+        p_tok = torch.randint(5, vocab, (int(p_off[-1]),), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+        t_tok = torch.randint(5, vocab, (int(t_off[-1]),), generator=g, device=dev, dtype=torch.int32).to(torch.int16)
+        pad1 = torch.zeros(1, dtype=torch.int32, device=dev)
+        self.n_docs, self.host, self.device = n_docs, None, dev
+        self.dev = dict(passage_tokens=p_tok, passage_off=p_off, title_tokens=t_tok, title_off=t_off,
+                        group_docs=(doc + 1).to(torch.int32), group_off=g_off, doc_group=torch.cat([pad1, doc_group]),
+                        doc_pos=torch.cat([pad1, doc_pos]))
+        st = _native.EvidenceArenaStruct()
+        for k, v in self.dev.items():
+            setattr(st, k, v.data_ptr())
+        st.n_docs = n_docs
+        self._struct = st
+        return self
+
     # ---- host views (compat path: the reference's `topk_data` structure) -------------------------------
     def passage(self, doc_id):
         h = self.host

@@ -30,10 +30,10 @@ def _check_bf16(*ts):
 
 # ---- raw kernels --------------------------------------------------------------------------------------------------------
 def gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None,
-            gelu=False, pre_act=None, residual=None):
+            gelu=False, pre_act=None, residual=None, split_k=1):
     _native.check(_lib().emdr2_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, batch1, sA1, sB1, sC1, batch2, sA2,
                                             sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual),
-                                            int(C.dtype == torch.float32), _sp()), "gemm_nt_bf16")
+                                            int(C.dtype == torch.float32), split_k, _sp()), "gemm_nt_bf16")
     return C
 
 
@@ -43,6 +43,18 @@ def matmul_nt(a, b, out_dtype=BF16, **kw):
     N = b.shape[0]
     c = torch.empty((M, N), dtype=out_dtype, device=a.device)
     return gemm_nt(a, K, b, K, c, N, M, N, K, **kw)
+
+
+def weight_grad_nt(dyT, xT):
+    """dW [N, K] fp32 = dyT [N, M] @ xT [K, M]^T : few output tiles, reduction over all tokens -> split the reduction across the chip."""
+    N, M = dyT.shape
+    Kd = xT.shape[0]
+    tiles = ((N + 255) // 256) * ((Kd + 255) // 256)
+    split = max(1, min(512 // max(tiles, 1), M // 4096))
+    if split == 1:
+        return matmul_nt(dyT, xT, out_dtype=torch.float32)
+    c = torch.zeros((N, Kd), dtype=torch.float32, device=dyT.device)
+    return gemm_nt(dyT, M, xT, M, c, Kd, N, Kd, M, split_k=split)
 
 
 def transpose(x2d, colsum=None):
@@ -162,7 +174,7 @@ class LinearFn(torch.autograd.Function):
             xT = transpose(x2)                                                            # [K, M]
             if M % 32:
                 raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
-            dW = matmul_nt(dyT, xT, out_dtype=torch.float32)                              # [N, K] fp32
+            dW = weight_grad_nt(dyT, xT)                                                  # [N, K] fp32 (split-K over the tokens)
             if ctx.row_perm is not None:                                                  # back to the checkpoint's interleaved row order
                 un = torch.empty_like(dW); un[ctx.row_perm] = dW; dW = un
                 if bias is not None:

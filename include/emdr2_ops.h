@@ -20,11 +20,13 @@ extern "C" {
  * (transformer.py:103-104; exact erf), bias-dropout-add at p = 0 (transformer.py:397-407).
  * K % 32 == 0; lda, ldb and the A/B batch strides multiples of 8 elements; A, B 16-byte aligned.
  * pre_act (optional, bf16, indexed like C): value before GELU, kept for the backward.
+ * split_k > 1: the reduction is cut into split_k slices accumulated with fp32 atomics into a PRE-ZEROED fp32 C (weight
+ * gradients: few output tiles, very long K); no epilogue options in that mode.
  */
 int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
                        int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
                        float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
-                       void *stream);
+                       int split_k, void *stream);
 
 /* out[b1,b2][c, r] = in[b1,b2][r, c] (bf16), optional fp32 column sums colsum[c] += sum_r in[r, c] over all batches
  * (bias gradients: the reduce of the reference's autograd over [s, b]). */

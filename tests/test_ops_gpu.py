@@ -24,7 +24,7 @@ def _gemm(A, B, bias=None, gelu=False, residual=None, alpha=1.0, out_f32=False, 
     nat.check(lib.emdr2_gemm_nt_bf16(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, batch, M * K, (N * K if B.dim() > 2 else 0), M * N,
                                      1, 0, 0, 0, alpha, bias.data_ptr() if bias is not None else None, int(gelu),
                                      pre.data_ptr() if pre is not None else None, residual.data_ptr() if residual is not None else None,
-                                     int(out_f32), nat.stream_ptr()), "gemm")
+                                     int(out_f32), 1, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     return (C, pre) if want_pre else C
 
@@ -72,7 +72,7 @@ def test_gemm_batched_two_levels_strided():
     q, k = qkv[:, :, 0], qkv[:, :, 1]
     ld = 3 * heads * hn
     nat.check(lib.emdr2_gemm_nt_bf16(q.data_ptr(), ld, k.data_ptr(), ld, scores.data_ptr(), s, s, s, hn, b, s * ld, s * ld, heads * s * s,
-                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, nat.stream_ptr()), "gemm")
+                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, 1, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     ref = torch.einsum("bqnd,bknd->bnqk", q.float(), k.float()) * 0.125
     assert torch.allclose(scores.float(), ref, rtol=2e-2, atol=5e-2)
@@ -89,3 +89,15 @@ def test_transpose_and_colsum():
     torch.cuda.synchronize()
     assert torch.equal(out, x.transpose(-1, -2).contiguous())
     assert torch.allclose(cs, x.float().sum((0, 1, 2)), rtol=1e-4, atol=1e-3)
+
+
+def test_weight_gradient_gemm_split_k():
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(21)
+    M, N, Kd = 65536, 768, 512
+    dyT = torch.randn((N, M), generator=g, device="cuda").bfloat16()
+    xT = torch.randn((Kd, M), generator=g, device="cuda").bfloat16()
+    dW = K.weight_grad_nt(dyT, xT)
+    torch.cuda.synchronize()
+    ref = dyT.float() @ xT.float().T
+    assert torch.allclose(dW, ref, rtol=2e-3, atol=0.5)
