@@ -96,37 +96,48 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const uint16_t *x, c
     }
 }
 
-// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional residual-branch gradient added on the way out;
-// dgamma/dbeta: per-block partial sums in LDS, one atomicAdd per column per block
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional residual-branch gradient added on the way out.
+// Block = 32 rows: phase 1 one wave per row computes the two row means into LDS; phase 2 every thread owns columns tid, tid+256, ...
+// for all 32 rows (dgamma / dbeta partials stay in registers; one global atomicAdd per column per block).
+#define LN_ROWS 32
 __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t *dy, const uint16_t *x, const float *gamma, const float *mean,
                                                             const float *rstd, const uint16_t *dres, uint16_t *dx, float *dgamma,
                                                             float *dbeta, long long rows, int H, int rows_per_block)
 {
-    extern __shared__ float part[]; // [2][H]
-    for (int i = threadIdx.x; i < 2 * H; i += 256) part[i] = 0.f;
-    __syncthreads();
+    __shared__ float s1s[LN_ROWS], s2s[LN_ROWS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long long r0 = (long long)blockIdx.x * rows_per_block;
-    for (long long row = r0 + wave; row < r0 + rows_per_block && row < rows; row += 4) {
-        const uint16_t *xr = x + row * H, *gr = dy + row * H;
-        const float mu = mean[row], rs = rstd[row];
+    const long long r0 = (long long)blockIdx.x * LN_ROWS;
+    for (int rr = wave; rr < LN_ROWS; rr += 4) {
+        const long long row = r0 + rr;
         float s1 = 0.f, s2 = 0.f;
-        for (int i = lane; i < H; i += 64) {
-            const float xh = (bf2f(xr[i]) - mu) * rs, g = bf2f(gr[i]) * gamma[i];
-            s1 += g; s2 += g * xh;
+        if (row < rows) {
+            const uint16_t *xr = x + row * H, *gr = dy + row * H;
+            const float mu = mean[row], rs = rstd[row];
+            for (int i = lane; i < H; i += 64) {
+                const float xh = (bf2f(xr[i]) - mu) * rs, g = bf2f(gr[i]) * gamma[i];
+                s1 += g; s2 += g * xh;
+            }
         }
-        s1 = wave_sum(s1) / H; s2 = wave_sum(s2) / H;
-        for (int i = lane; i < H; i += 64) {
-            const float xh = (bf2f(xr[i]) - mu) * rs, d = bf2f(gr[i]);
-            float v = rs * (d * gamma[i] - s1 - xh * s2);
-            if (dres) v += bf2f(dres[row * H + i]);
-            dx[row * H + i] = f2bf(v);
-            atomicAdd(&part[i], d * xh);
-            atomicAdd(&part[H + i], d);
-        }
+        s1 = wave_sum(s1); s2 = wave_sum(s2);
+        if (lane == 0) { s1s[rr] = s1 / H; s2s[rr] = s2 / H; }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < H; i += 256) { atomicAdd(&dgamma[i], part[i]); atomicAdd(&dbeta[i], part[H + i]); }
+    for (int c = threadIdx.x; c < H; c += 256) {
+        const float gm = gamma[c];
+        float ag = 0.f, ab = 0.f;
+        for (int rr = 0; rr < LN_ROWS; ++rr) {
+            const long long row = r0 + rr;
+            if (row >= rows) break;
+            const float mu = mean[row], rs = rstd[row];
+            const float xh = (bf2f(x[row * H + c]) - mu) * rs, d = bf2f(dy[row * H + c]);
+            float v = rs * (d * gm - s1s[rr] - xh * s2s[rr]);
+            if (dres) v += bf2f(dres[row * H + c]);
+            dx[row * H + c] = f2bf(v);
+            ag += d * xh; ab += d;
+        }
+        atomicAdd(&dgamma[c], ag);
+        atomicAdd(&dbeta[c], ab);
+    }
 }
 
 // ---- masked softmax over the last dim (reference fallback path: fused_softmax.py:113-125, mask value -10000 REPLACES the score) --
@@ -161,6 +172,109 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const lon
         sr[k] = f2bf(__expf((masked ? -10000.f : bf2f(sr[k])) - m) * inv);
     }
     if (lane == 0 && mstat) { mstat[row] = m; lstat[row] = l; }
+}
+
+// register-resident variants (sk % 8 == 0, sk <= 2048): one HBM read + one write per element, 16-byte accesses
+template <int NV>
+__global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const long long *ids_q, const long long *ids_k, int np, int sq, int sk,
+                                                              int causal, float *mstat, float *lstat, long long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % sq);
+    const long long b = row / ((long long)sq * np);
+    const bool qpad = ids_q[b * sq + q] == 0;
+    uint16_t *sr = s + row * sk;
+    const long long *kid = ids_k + b * sk;
+    float v[NV][8];
+    float m = -3.0e38f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        if (k0 < sk) {
+            const uint4 x = *(const uint4 *)(sr + k0);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+                v[i][j] = masked ? -10000.f : bf2f((uint16_t)((j & 1) ? w[j >> 1] >> 16 : w[j >> 1] & 0xffff));
+                m = fmaxf(m, v[i][j]);
+            }
+        }
+    }
+    m = wave_max(m);
+    float l = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if ((i * 64 + lane) * 8 < sk) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[i][j] = __expf(v[i][j] - m); l += v[i][j]; }
+        }
+    l = wave_sum(l);
+    const float inv = 1.f / l;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        if (k0 < sk) {
+            uint32_t w[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[i][2 * j] * inv) | ((uint32_t)f2bf(v[i][2 * j + 1] * inv) << 16);
+            *(uint4 *)(sr + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    if (lane == 0 && mstat) { mstat[row] = m; lstat[row] = l; }
+}
+
+template <int NV>
+__global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p, uint16_t *dp, const long long *ids_q, const long long *ids_k, int np,
+                                                              int sq, int sk, int causal, float *dstat, long long rows)
+{
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int q = (int)(row % sq);
+    const long long b = row / ((long long)sq * np);
+    const bool qpad = ids_q[b * sq + q] == 0;
+    const long long *kid = ids_k + b * sk;
+    const uint16_t *pr = p + row * sk;
+    uint16_t *dr = dp + row * sk;
+    float pv[NV][8], gv[NV][8];
+    float d = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        if (k0 < sk) {
+            const uint4 a = *(const uint4 *)(pr + k0), g = *(const uint4 *)(dr + k0);
+            const uint32_t aw[4] = {a.x, a.y, a.z, a.w}, gw[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                pv[i][j] = bf2f((uint16_t)((j & 1) ? aw[j >> 1] >> 16 : aw[j >> 1] & 0xffff));
+                gv[i][j] = bf2f((uint16_t)((j & 1) ? gw[j >> 1] >> 16 : gw[j >> 1] & 0xffff));
+                d += pv[i][j] * gv[i][j];
+            }
+        }
+    }
+    d = wave_sum(d);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int k0 = (i * 64 + lane) * 8;
+        if (k0 < sk) {
+            uint32_t w[4];
+            float o[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = k0 + j;
+                const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+                o[j] = masked ? 0.f : pv[i][j] * (gv[i][j] - d);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(o[2 * j]) | ((uint32_t)f2bf(o[2 * j + 1]) << 16);
+            *(uint4 *)(dr + k0) = make_uint4(w[0], w[1], w[2], w[3]);
+        }
+    }
+    if (lane == 0 && dstat) dstat[row] = d;
 }
 
 // dS = P * (dP - sum_k P*dP), in place on dP; masked positions get the same formula (their P is ~0 unless the row is fully
@@ -368,8 +482,8 @@ extern "C" int emdr2_layernorm_bwd(const void *dy, const void *x, const float *g
                                    void *dx, float *dgamma, float *dbeta, int64_t rows, int H, void *stream)
 {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 1 || H < 1 || H > 8192) return -1;
-    const int rpb = 64;
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 2 * H * sizeof(float), (hipStream_t)stream,
+    const int rpb = LN_ROWS;
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)dy, (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta,
                        (long long)rows, H, rpb);
     return LAUNCH_OK();
@@ -380,8 +494,16 @@ extern "C" int emdr2_softmax_mask_fwd(void *scores, const int64_t *ids_q, const 
 {
     if (!scores || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
     const long long rows = (long long)batch * heads * sq;
-    hipLaunchKernelGGL(softmax_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores,
-                       (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    if (!(sk & 7) && sk <= 512 && !((uintptr_t)scores & 15))
+        hipLaunchKernelGGL(softmax_fwd_reg_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+    else if (!(sk & 7) && sk <= 2048 && !((uintptr_t)scores & 15))
+        hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+    else
+        hipLaunchKernelGGL(softmax_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
     return LAUNCH_OK();
 }
 
@@ -390,8 +512,17 @@ extern "C" int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int
 {
     if (!probs || !dprobs || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
     const long long rows = (long long)batch * heads * sq;
-    hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs,
-                       (uint16_t *)dprobs, (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+    const dim3 grid((unsigned)((rows + 3) / 4));
+    const bool al = !((uintptr_t)probs & 15) && !((uintptr_t)dprobs & 15);
+    if (!(sk & 7) && sk <= 512 && al)
+        hipLaunchKernelGGL(softmax_bwd_reg_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+    else if (!(sk & 7) && sk <= 2048 && al)
+        hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+    else
+        hipLaunchKernelGGL(softmax_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
     return LAUNCH_OK();
 }
 

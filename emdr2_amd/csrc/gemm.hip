@@ -43,7 +43,9 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f)
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
-template <int WM, int WN>
+// VEC: bf16 output staged through LDS per wave and written as 16-byte row segments (bias / GELU / pre-activation / residual
+// applied on 8-element vectors); otherwise (fp32 output, split-K atomics, unaligned leading dimensions) the scalar epilogue.
+template <int WM, int WN, bool VEC>
 __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
 {
     constexpr int BM = WM * 64, BN = WN * 128;
@@ -143,6 +145,60 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two speculative chunks
 
+    if (VEC) {
+        // ---- vector epilogue: acc -> LDS (fp32, wave-private 32 x 128 half tile, pitch 132) -> 8-wide row segments ----------
+        __syncthreads();                                           // every wave is done with the operand ring
+        float *wl = (float *)smem + wave * (32 * 132);
+        const int seg = lane & 15, rsub = lane >> 4;               // 16 lanes cover one 128-column row, 4 rows per pass
+        const int ncol = n0 + wn * 128 + seg * 8;
+        float bv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) bv[j] = (p.bias && ncol + j < p.N) ? p.bias[ncol + j] : 0.f;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    wl[((r & 3) + 8 * (r >> 2) + 4 * hi) * 132 + ni * 32 + l31] = acc[mi][ni][r];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const int rl = g * 4 + rsub;
+                const int m = m0 + wm * 64 + mi * 32 + rl;
+                const float4 lo = *(const float4 *)(wl + rl * 132 + seg * 8), hi4 = *(const float4 *)(wl + rl * 132 + seg * 8 + 4);
+                float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
+                if (m < p.M && ncol < p.N) {
+                    const long long o = coff + (long long)m * p.ldc + ncol;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bv[j];
+                    if (p.C2) {
+                        uint32_t w[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
+                        *(uint4 *)((uint16_t *)p.C2 + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    }
+                    if (p.gelu) {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+                    }
+                    if (p.R) {
+                        const uint4 rr = *(const uint4 *)((const uint16_t *)p.R + o);
+                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) { v[2 * j] += bf16_to_f32((uint16_t)(rw[j] & 0xffff)); v[2 * j + 1] += bf16_to_f32((uint16_t)(rw[j] >> 16)); }
+                    }
+                    uint32_t w[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
+                    *(uint4 *)((uint16_t *)p.C + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this half are done before the next half overwrites
+        }
+        return;
+    }
+
     // epilogue.  C layout of the 32x32 MFMA: column n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const int mrow0 = m0 + wm * 64 + 4 * hi;
     const int ncol0 = n0 + wn * 128 + l31;
@@ -170,19 +226,28 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     }
 }
 
-template <int WM, int WN>
-static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
+template <int WM, int WN, bool VEC>
+static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
 {
     constexpr int BM = WM * 64, BN = WN * 128;
-    constexpr int LDS = GNST * (BM + BN) * 64;
+    constexpr int RING = GNST * (BM + BN) * 64, STAGING = 8 * 32 * 132 * 4;
+    constexpr int LDS = (VEC && STAGING > RING) ? STAGING : RING;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_done = true;
     }
     dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN>), grid, dim3(512), LDS, stream, p);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+template <int WM, int WN>
+static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
+{
+    const bool vec = !p.out_f32 && p.splitk == 1 && !(p.ldc & 7) && !(p.N & 7) && !(p.sC1 & 7) && !(p.sC2 & 7) && !((uintptr_t)p.C & 15) &&
+                     !((uintptr_t)p.C2 & 15) && !((uintptr_t)p.R & 15);
+    return vec ? launch_gemm_v<WM, WN, true>(p, batch, stream) : launch_gemm_v<WM, WN, false>(p, batch, stream);
 }
 
 extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
