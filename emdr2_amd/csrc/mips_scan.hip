@@ -125,10 +125,14 @@ __global__ void __launch_bounds__(512) mips_scan_kernel(ScanParams p)
                     __syncthreads();
                 }
             }
-            issue();
+            // where in the chunk this wave issues its LDS-DMA pieces (p.tune bit 3): the two waves of a SIMD at different points,
+            // so a wave stalled in a back-pressured VMEM issue has a partner that is issuing MFMAs
+            const int ipos = (p.tune & 8) ? (wave >> 2) : 0;
+            if (ipos == 0) issue();
             const char *sb = smem + cs * STAGE;
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
+                if (ks == 1 && ipos == 1) issue();
                 half8 a[2], b[4];
                 if (ABL == 2) {
 #pragma unroll

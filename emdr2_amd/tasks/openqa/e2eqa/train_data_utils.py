@@ -1,0 +1,59 @@
+"""Batch layout of the QA task (reference: tasks/openqa/e2eqa/train_data_utils.py:27-81,128-150 and the collate of
+train_e2eqa.py:51-68).  Host-side int64 list building, unchanged in meaning: question -> [CLS] q [SEP] pad (S_ret),
+answer -> dec_ids = [BOS] a pad, labels = a [EOS] pad, loss_mask (L)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+
+def build_tokens_types_paddings_from_ids(src_ids, answer_text_ids, max_seq_length, decoder_seq_length, cls_id, sep_id, pad_id, bos_id, eos_id):
+    enc_ids = [cls_id] + list(src_ids)
+    tokentypes_enc = [0] * len(enc_ids)
+    if len(enc_ids) > max_seq_length - 1:
+        enc_ids = enc_ids[0: max_seq_length - 1]
+        tokentypes_enc = tokentypes_enc[0: max_seq_length - 1]
+    enc_ids.append(sep_id)
+    tokentypes_enc.append(0)
+    num_tokens_enc = len(enc_ids)
+    padding_length = max_seq_length - len(enc_ids)
+    if padding_length > 0:
+        enc_ids.extend([pad_id] * padding_length)
+        tokentypes_enc.extend([pad_id] * padding_length)
+
+    dec_in_ids, dec_out_ids = [bos_id] + list(answer_text_ids), list(answer_text_ids)
+    if len(dec_in_ids) > decoder_seq_length:
+        dec_in_ids = dec_in_ids[0: decoder_seq_length]
+        dec_out_ids = dec_out_ids[0: decoder_seq_length - 1]
+    dec_out_ids.append(eos_id)
+    num_tokens_dec = len(dec_in_ids)
+    padding_length_dec = decoder_seq_length - num_tokens_dec
+    assert padding_length_dec >= 0
+    dec_in_ids.extend([pad_id] * padding_length_dec)
+    dec_out_ids.extend([pad_id] * padding_length_dec)
+    loss_mask = ([1] * num_tokens_dec) + ([0] * padding_length_dec)
+    return enc_ids, tokentypes_enc, num_tokens_enc, dec_in_ids, dec_out_ids, loss_mask
+
+
+def build_sample(query_uid, question_ids, answer_ids, seq_length_ret, decoder_seq_length, cls_id, sep_id, pad_id, bos_id, eos_id, reference=None):
+    """One dataset item with the reference's 10 keys (train_data_utils.py:152-173)."""
+    enc, types, n_enc, dec_in, dec_out, loss_mask = build_tokens_types_paddings_from_ids(
+        question_ids, answer_ids, seq_length_ret, decoder_seq_length, cls_id, sep_id, pad_id, bos_id, eos_id)
+    ids = np.array(enc, dtype=np.int64)
+    mask2d = ((ids[None, :] >= 1) * (ids[:, None] >= 1)).astype(np.int64)        # make_attention_mask (mask_creation_utils.py:5-14)
+    return OrderedDict(query_uid=query_uid, query_ids_bert=enc, query_types=types, query_mask_bert=mask2d, query_ids_t5=enc,
+                       query_ids_t5_len=n_enc, dec_ids=dec_in, labels=dec_out, loss_mask=loss_mask, reference=reference)
+
+
+def collate(batch_data):
+    """CustomDataLoader._collate_fn (train_e2eqa.py:51-68)."""
+    t = OrderedDict()
+    for d in batch_data:
+        for k, v in d.items():
+            t.setdefault(k, []).append(v)
+    assert len(t) == 10
+    for k in ("query_uid", "query_ids_bert", "query_types", "query_ids_t5", "query_ids_t5_len", "dec_ids", "labels"):
+        t[k] = torch.tensor(np.array(t[k]), dtype=torch.int64)
+    t["query_mask_bert"] = torch.tensor(np.array(t["query_mask_bert"]), dtype=torch.int64)
+    t["loss_mask"] = torch.tensor(np.array(t["loss_mask"]), dtype=torch.float32)
+    return t

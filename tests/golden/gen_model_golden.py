@@ -197,3 +197,21 @@ def main():
 
 if __name__ == "__main__":
     main()
+
+
+def a1_fixture():
+    """F-a1: the reference's QA batch builder (tasks/openqa/e2eqa/train_data_utils.py:27-81) on edge cases."""
+    _ref_import.install_import_shims()
+    from tasks.openqa.e2eqa.train_data_utils import build_tokens_types_paddings_from_ids as ref
+    rng = np.random.default_rng(3)
+    cases, outs = [], []
+    for qn, an in ((5, 2), (30, 1), (22, 9), (40, 7), (3, 12), (23, 8)):
+        q, a = rng.integers(5, 200, size=qn).tolist(), rng.integers(5, 200, size=an).tolist()
+        cases.append((q, a))
+        outs.append(ref(q, a, 24, 8, 2, 3, 0, 250, 251))
+    np.savez_compressed(os.path.join(HERE, "a1_ref.npz"), cases=np.array(cases, dtype=object), outs=np.array(outs, dtype=object), allow_pickle=True)
+    print("saved a1_ref.npz")
+
+
+if __name__ == "__main__" and os.environ.get("EMDR2_GEN_A1"):
+    a1_fixture()
