@@ -48,6 +48,7 @@ def main():
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--seq-ret", type=int, default=256)
+    ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (the reference's default, arguments.py)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
@@ -78,7 +79,8 @@ def main():
     retr.topk, retr.mips_index, retr.arena, retr.process_group = K, index, arena, None
 
     torch.manual_seed(1234)
-    cfg = Config(num_layers=args.layers, hidden_size=H, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512, init_method_std=0.02)
+    cfg = Config(num_layers=args.layers, hidden_size=H, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512, init_method_std=0.02,
+                 hidden_dropout=args.dropout, attention_dropout=args.dropout)
     model = EMDR2Model(retr, cfg, V_T5, V_BERT, K, S, S_ret, cls_id=101, sep_id=102, checkpoint_activations=True)
     model.train()
     opt = FusedAdam(get_params_for_weight_decay_optimization(model), lr=2e-5, weight_decay=0.1, clip_grad=1.0)
@@ -142,7 +144,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                    % (B, K, S_ret, S, L, args.rows, args.layers),
                        "global_batch": B * world, "params": n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
-                       "dropout": 0.0, "activation_recompute": "per layer", "loss": float(loss)},
+                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss)},
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
                          "traffic": None, "flops_per_step_per_gpu": fl, "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"},
         }), flush=True)

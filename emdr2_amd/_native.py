@@ -40,20 +40,24 @@ SIGNATURES["emdr2_assemble_evidence"] = (_i32, [_vp, _vp, _i32, _i32, _i32, _vp,
 
 
 _f32 = ctypes.c_float
+_u32 = ctypes.c_uint32
 SIGNATURES["emdr2_gemm_nt_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _i64,
-                                             _f32, _vp, _i32, _vp, _vp, _i32, _i32, _vp])
+                                             _f32, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _u32, _vp])
+SIGNATURES["emdr2_dropout"] = (_i32, [_vp, _vp, _i64, _f32, _u32, _vp])
 SIGNATURES["emdr2_transpose_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _vp, _vp])
 
 
 SIGNATURES.update({
     "emdr2_layernorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "emdr2_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
-    "emdr2_softmax_mask_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "emdr2_softmax_mask_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
-    "emdr2_softmax_mask_t": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "emdr2_softmax_mask_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _u32, _vp]),
+    "emdr2_softmax_mask_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _u32, _vp, _vp]),
+    "emdr2_softmax_mask_t": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _u32, _vp]),
     "emdr2_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
-    "emdr2_embedding_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "emdr2_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "emdr2_embedding_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "emdr2_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "emdr2_attention_fwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                   _f32, _f32, _u32, _vp, _vp, _vp]),
     "emdr2_lse_gather_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "emdr2_lse_gather_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "emdr2_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp]),

@@ -2,6 +2,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rng.h"
 
 namespace {
 
@@ -144,7 +145,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t *dy, 
 // masked(b, q, k) = ids_q[b,q] == 0 || ids_k[b,k] == 0 || (causal && k > q)     (mask_creation_utils.py:17-42, pad id 0)
 // scores [B, np, sq, sk] bf16 in place -> probs; stats m, l fp32 [B, np, sq] (row max and sum of exp), one wave per row
 __global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const long long *ids_q, const long long *ids_k, int np, int sq, int sk,
-                                                          int causal, float *mstat, float *lstat, long long rows)
+                                                          int causal, float *mstat, float *lstat, long long rows, float drop_p, uint32_t seed)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -169,7 +170,9 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const lon
     const float inv = 1.f / l;
     for (int k = lane; k < sk; k += 64) {
         const bool masked = qpad || kid[k] == 0 || (causal && k > q);
-        sr[k] = f2bf(__expf((masked ? -10000.f : bf2f(sr[k])) - m) * inv);
+        float pv = __expf((masked ? -10000.f : bf2f(sr[k])) - m) * inv;
+        if (drop_p > 0.f) pv = emdr2_keep(seed, (unsigned long long)row * sk + k, drop_p) ? pv / (1.f - drop_p) : 0.f;
+        sr[k] = f2bf(pv);
     }
     if (lane == 0 && mstat) { mstat[row] = m; lstat[row] = l; }
 }
@@ -177,7 +180,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const lon
 // register-resident variants (sk % 8 == 0, sk <= 2048): one HBM read + one write per element, 16-byte accesses
 template <int NV>
 __global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const long long *ids_q, const long long *ids_k, int np, int sq, int sk,
-                                                              int causal, float *mstat, float *lstat, long long rows)
+                                                              int causal, float *mstat, float *lstat, long long rows, float drop_p, uint32_t seed)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -214,11 +217,16 @@ __global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const
         }
     l = wave_sum(l);
     const float inv = 1.f / l;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k0 = (i * 64 + lane) * 8;
         if (k0 < sk) {
             uint32_t w[4];
+            if (drop_p > 0.f) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[i][j] = emdr2_keep(seed, (unsigned long long)row * sk + k0 + j, drop_p) ? v[i][j] * ik : 0.f;
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[i][2 * j] * inv) | ((uint32_t)f2bf(v[i][2 * j + 1] * inv) << 16);
             *(uint4 *)(sr + k0) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -229,7 +237,8 @@ __global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const
 
 template <int NV>
 __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p, uint16_t *dp, const long long *ids_q, const long long *ids_k, int np,
-                                                              int sq, int sk, int causal, float *dstat, long long rows)
+                                                              int sq, int sk, int causal, float *dstat, long long rows, const float *mstat,
+                                                              const float *lstat, float drop_p, uint32_t seed)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -242,6 +251,8 @@ __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p,
     uint16_t *dr = dp + row * sk;
     float pv[NV][8], gv[NV][8];
     float d = 0.f;
+    const float ms = mstat ? mstat[row] : 0.f, il = mstat ? 1.f / lstat[row] : 1.f;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k0 = (i * 64 + lane) * 8;
@@ -252,6 +263,12 @@ __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p,
             for (int j = 0; j < 8; ++j) {
                 pv[i][j] = bf2f((uint16_t)((j & 1) ? aw[j >> 1] >> 16 : aw[j >> 1] & 0xffff));
                 gv[i][j] = bf2f((uint16_t)((j & 1) ? gw[j >> 1] >> 16 : gw[j >> 1] & 0xffff));
+                if (mstat) {                                             // p holds raw scaled scores: rebuild the probability from the row statistics
+                    const int k = k0 + j;
+                    const bool masked = qpad || kid[k] == 0 || (causal && k > q);
+                    pv[i][j] = __expf((masked ? -10000.f : pv[i][j]) - ms) * il;
+                }
+                if (drop_p > 0.f) gv[i][j] = emdr2_keep(seed, (unsigned long long)row * sk + k0 + j, drop_p) ? gv[i][j] * ik : 0.f;
                 d += pv[i][j] * gv[i][j];
             }
         }
@@ -281,7 +298,8 @@ __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p,
 // masked, where the reference's autograd also flows a uniform-softmax gradient into the replaced (constant) scores: those
 // are zeroed because masked_fill breaks the dependence on the score).  D[row] is also written.
 __global__ void __launch_bounds__(256) softmax_bwd_kernel(const uint16_t *p, uint16_t *dp, const long long *ids_q, const long long *ids_k,
-                                                          int np, int sq, int sk, int causal, float *dstat, long long rows)
+                                                          int np, int sq, int sk, int causal, float *dstat, long long rows, const float *mstat,
+                                                          const float *lstat, float drop_p, uint32_t seed)
 {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -293,11 +311,15 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const uint16_t *p, uin
     const uint16_t *pr = p + row * sk;
     uint16_t *dr = dp + row * sk;
     float d = 0.f;
-    for (int k = lane; k < sk; k += 64) d += bf2f(pr[k]) * bf2f(dr[k]);
+    const float ms = mstat ? mstat[row] : 0.f, il = mstat ? 1.f / lstat[row] : 1.f;
+    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    auto prob = [&](int k, bool masked) { return mstat ? __expf((masked ? -10000.f : bf2f(pr[k])) - ms) * il : bf2f(pr[k]); };
+    auto grad = [&](int k) { const float g = bf2f(dr[k]); return drop_p > 0.f ? (emdr2_keep(seed, (unsigned long long)row * sk + k, drop_p) ? g * ik : 0.f) : g; };
+    for (int k = lane; k < sk; k += 64) d += prob(k, qpad || kid[k] == 0 || (causal && k > q)) * grad(k);
     d = wave_sum(d);
     for (int k = lane; k < sk; k += 64) {
         const bool masked = qpad || kid[k] == 0 || (causal && k > q);
-        dr[k] = masked ? (uint16_t)0 : f2bf(bf2f(pr[k]) * (bf2f(dr[k]) - d));
+        dr[k] = masked ? (uint16_t)0 : f2bf(prob(k, masked) * (grad(k) - d));
     }
     if (lane == 0 && dstat) dstat[row] = d;
 }
@@ -307,7 +329,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const uint16_t *p, uin
 // dS^T = masked ? 0 : P^T * (dP^T - D[q]).  Writes P^T over S^T and dS^T over dP^T.  Elementwise, 8 elements per thread.
 __global__ void __launch_bounds__(256) softmax_t_kernel(uint16_t *st, uint16_t *dpt, const long long *ids_q, const long long *ids_k,
                                                         const float *mstat, const float *lstat, const float *dstat, int np, int sq,
-                                                        int sk, int causal, long long total)
+                                                        int sk, int causal, long long total, float drop_p, uint32_t seed)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     if (i >= total) return;
@@ -319,8 +341,15 @@ __global__ void __launch_bounds__(256) softmax_t_kernel(uint16_t *st, uint16_t *
     const long long srow = bn * sq + q;      // stats index
     const bool masked = ids_q[b * sq + q] == 0 || ids_k[b * sk + k] == 0 || (causal && k > q);
     const float pt = __expf((masked ? -10000.f : bf2f(st[i])) - mstat[srow]) / lstat[srow];
-    st[i] = f2bf(pt);
-    dpt[i] = masked ? (uint16_t)0 : f2bf(pt * (bf2f(dpt[i]) - dstat[srow]));
+    float g = bf2f(dpt[i]), pd = pt;
+    if (drop_p > 0.f) {
+        const bool keep = emdr2_keep(seed, (unsigned long long)srow * sk + k, drop_p);
+        const float ik = 1.f / (1.f - drop_p);
+        g = keep ? g * ik : 0.f;
+        pd = keep ? pt * ik : 0.f;                                        // dropped probabilities (what multiplied V in the forward) for dV
+    }
+    st[i] = f2bf(pd);
+    dpt[i] = masked ? (uint16_t)0 : f2bf(pt * (g - dstat[srow]));
 }
 
 // ---- GELU backward on the saved pre-activation (exact erf form; transformer.py:80,103-104) -------------------------------
@@ -347,7 +376,7 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const uint16_t *pre, cons
 
 // ---- embedding (language_model.py:169-181): out = W[ids] + P[pos] (+ T[types]) ------------------------------------------------
 __global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids, const long long *types, const uint16_t *W, const uint16_t *P,
-                                                            const uint16_t *T, uint16_t *out, long long tokens, int S, int H)
+                                                            const uint16_t *T, uint16_t *out, long long tokens, int S, int H, float drop_p, uint32_t seed)
 {
     const long long t = blockIdx.x;
     const long long id = ids[t], pos = t % S;
@@ -355,22 +384,42 @@ __global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = bf2f(W[id * H + i]) + bf2f(P[pos * H + i]);
         if (types) v += bf2f(T[ty * H + i]);
+        if (drop_p > 0.f) v = emdr2_keep(seed, (unsigned long long)(t * H + i), drop_p) ? v / (1.f - drop_p) : 0.f;
         out[t * H + i] = f2bf(v);
     }
 }
 
 __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids, const long long *types, const uint16_t *dout, float *dW, float *dP,
-                                                            float *dT, long long tokens, int S, int H)
+                                                            float *dT, long long tokens, int S, int H, float drop_p, uint32_t seed)
 {
     const long long t = blockIdx.x;
     const long long id = ids[t], pos = t % S;
     const long long ty = types ? types[t] : 0;
     for (int i = threadIdx.x; i < H; i += 256) {
-        const float g = bf2f(dout[t * H + i]);
+        float g = bf2f(dout[t * H + i]);
+        if (drop_p > 0.f) g = emdr2_keep(seed, (unsigned long long)(t * H + i), drop_p) ? g / (1.f - drop_p) : 0.f;
         atomicAdd(&dW[id * H + i], g);
         atomicAdd(&dP[pos * H + i], g);
         if (types) atomicAdd(&dT[ty * H + i], g);
     }
+}
+
+// ---- dropout mask of a site re-applied to a contiguous bf16 tensor (backward of the fused bias-dropout-add epilogue) --------------
+__global__ void __launch_bounds__(256) dropout_kernel(const uint16_t *x, uint16_t *out, long long n, float drop_p, uint32_t seed)
+{
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    if (i >= n) return;
+    const float ik = 1.f / (1.f - drop_p);
+    const uint4 a = *(const uint4 *)(x + i);
+    const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
+    uint32_t w[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float lo = emdr2_keep(seed, (unsigned long long)(i + 2 * j), drop_p) ? bf2f((uint16_t)(aw[j] & 0xffff)) * ik : 0.f;
+        const float hi = emdr2_keep(seed, (unsigned long long)(i + 2 * j + 1), drop_p) ? bf2f((uint16_t)(aw[j] >> 16)) * ik : 0.f;
+        w[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+    }
+    *(uint4 *)(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
 }
 
 // ---- log-softmax + gather over the vocabulary (train_e2eqa.py:72-123,152-160) --------------------------------------------------
@@ -490,49 +539,52 @@ extern "C" int emdr2_layernorm_bwd(const void *dy, const void *x, const float *g
 }
 
 extern "C" int emdr2_softmax_mask_fwd(void *scores, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int causal,
-                                      float *m, float *l, void *stream)
+                                      float *m, float *l, float drop_p, uint32_t seed, void *stream)
 {
+    if (drop_p < 0.f || drop_p >= 1.f) return -1;
     if (!scores || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
     const long long rows = (long long)batch * heads * sq;
     const dim3 grid((unsigned)((rows + 3) / 4));
     if (!(sk & 7) && sk <= 512 && !((uintptr_t)scores & 15))
         hipLaunchKernelGGL(softmax_fwd_reg_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
-                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows, drop_p, seed);
     else if (!(sk & 7) && sk <= 2048 && !((uintptr_t)scores & 15))
         hipLaunchKernelGGL(softmax_fwd_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
-                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows, drop_p, seed);
     else
         hipLaunchKernelGGL(softmax_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores, (const long long *)ids_q,
-                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows);
+                           (const long long *)ids_k, heads, sq, sk, causal, m, l, rows, drop_p, seed);
     return LAUNCH_OK();
 }
 
-extern "C" int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq,
-                                      int sk, int causal, float *d, void *stream)
+extern "C" int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l,
+                                      int batch, int heads, int sq, int sk, int causal, float drop_p, uint32_t seed, float *d, void *stream)
 {
+    if (drop_p < 0.f || drop_p >= 1.f || (m && !l) || (drop_p > 0.f && !m)) return -1;
     if (!probs || !dprobs || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
     const long long rows = (long long)batch * heads * sq;
     const dim3 grid((unsigned)((rows + 3) / 4));
     const bool al = !((uintptr_t)probs & 15) && !((uintptr_t)dprobs & 15);
     if (!(sk & 7) && sk <= 512 && al)
         hipLaunchKernelGGL(softmax_bwd_reg_kernel<1>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
-                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows, m, l, drop_p, seed);
     else if (!(sk & 7) && sk <= 2048 && al)
         hipLaunchKernelGGL(softmax_bwd_reg_kernel<4>, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
-                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows, m, l, drop_p, seed);
     else
         hipLaunchKernelGGL(softmax_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const uint16_t *)probs, (uint16_t *)dprobs,
-                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows);
+                           (const long long *)ids_q, (const long long *)ids_k, heads, sq, sk, causal, d, rows, m, l, drop_p, seed);
     return LAUNCH_OK();
 }
 
 extern "C" int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l,
-                                    const float *d, int batch, int heads, int sq, int sk, int causal, void *stream)
+                                    const float *d, int batch, int heads, int sq, int sk, int causal, float drop_p, uint32_t seed, void *stream)
 {
+    if (drop_p < 0.f || drop_p >= 1.f) return -1;
     if (!scores_t || !dprobs_t || !ids_q || !ids_k || !m || !l || !d || batch < 1 || heads < 1 || sq < 1 || sk < 1) return -1;
     const long long total = (long long)batch * heads * sq * sk;
     hipLaunchKernelGGL(softmax_t_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (uint16_t *)scores_t,
-                       (uint16_t *)dprobs_t, (const long long *)ids_q, (const long long *)ids_k, m, l, d, heads, sq, sk, causal, total);
+                       (uint16_t *)dprobs_t, (const long long *)ids_q, (const long long *)ids_k, m, l, d, heads, sq, sk, causal, total, drop_p, seed);
     return LAUNCH_OK();
 }
 
@@ -545,20 +597,28 @@ extern "C" int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int
 }
 
 extern "C" int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, const void *W, const void *P, const void *T, void *out, int64_t tokens,
-                                   int S, int H, void *stream)
+                                   int S, int H, float drop_p, uint32_t seed, void *stream)
 {
-    if (!ids || !W || !P || !out || tokens < 1 || S < 1 || H < 1 || (types && !T)) return -1;
+    if (!ids || !W || !P || !out || tokens < 1 || S < 1 || H < 1 || (types && !T) || drop_p < 0.f || drop_p >= 1.f) return -1;
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
-                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)tokens, S, H);
+                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)tokens, S, H, drop_p, seed);
     return LAUNCH_OK();
 }
 
 extern "C" int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S,
-                                   int H, void *stream)
+                                   int H, float drop_p, uint32_t seed, void *stream)
 {
-    if (!ids || !dout || !dW || !dP || tokens < 1 || S < 1 || H < 1 || (types && !dT)) return -1;
+    if (!ids || !dout || !dW || !dP || tokens < 1 || S < 1 || H < 1 || (types && !dT) || drop_p < 0.f || drop_p >= 1.f) return -1;
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
-                       (const uint16_t *)dout, dW, dP, dT, (long long)tokens, S, H);
+                       (const uint16_t *)dout, dW, dP, dT, (long long)tokens, S, H, drop_p, seed);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, float drop_p, uint32_t seed, void *stream)
+{
+    if (!x || !out || n < 8 || (n & 7) || drop_p <= 0.f || drop_p >= 1.f || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return -1;
+    hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, (uint16_t *)out,
+                       (long long)n, drop_p, seed);
     return LAUNCH_OK();
 }
 

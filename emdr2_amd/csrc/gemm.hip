@@ -12,6 +12,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "rng.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -30,6 +31,8 @@ struct GemmParams {
     int M, N, K, batch2;
     float alpha;
     int gelu, out_f32;
+    float drop_p;             // dropout on (acc*alpha + bias [gelu]) before the residual add: bias_dropout_add (transformer.py:397-413)
+    uint32_t seed;            // keep bit = emdr2_keep(seed, m * N + n)
     int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
 
@@ -182,6 +185,11 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
                     }
+                    if (p.drop_p > 0.f) {
+                        const float ik = 1.f / (1.f - p.drop_p);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = emdr2_keep(p.seed, (unsigned long long)m * p.N + ncol + j, p.drop_p) ? v[j] * ik : 0.f;
+                    }
                     if (p.R) {
                         const uint4 rr = *(const uint4 *)((const uint16_t *)p.R + o);
                         const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
@@ -217,6 +225,7 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
                 float v = acc[mi][ni][r] * p.alpha + bias;
                 if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
                 if (p.gelu) v = gelu_erf(v);
+                if (p.drop_p > 0.f) v = emdr2_keep(p.seed, (unsigned long long)m * p.N + n, p.drop_p) ? v / (1.f - p.drop_p) : 0.f;
                 if (p.R) v += bf16_to_f32(((const uint16_t *)p.R)[o]);
                 if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
                 else if (p.out_f32) ((float *)p.C)[o] = v;
@@ -253,8 +262,9 @@ static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
 extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
                                   int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
                                   float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
-                                  int split_k, void *stream)
+                                  int split_k, float drop_p, uint32_t seed, void *stream)
 {
+    if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (batch1 * batch2 != 1 || split_k > 1))) return -1;
     if (!A || !B || !C || M < 1 || N < 1 || K < 32 || (K & 31) || batch1 < 1 || batch2 < 1 || split_k < 1) return -1;
     if (split_k > 1 && (!out_f32 || bias || gelu || pre_act || residual)) return -1;
     if ((lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return -1;
@@ -264,7 +274,7 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     p.bias = bias; p.R = (const char *)residual;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
-    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k;
+    p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k; p.drop_p = drop_p; p.seed = seed;
     const int batch = batch1 * batch2;
     if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
     if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);

@@ -108,7 +108,7 @@ class EMDR2Model(torch.nn.Module):
     kernels, so `query_mask_bert` is accepted for signature compatibility and ignored."""
 
     def __init__(self, evidence_retriever, cfg, t5_vocab_size, bert_vocab_size, topk, seq_length, seq_length_ret, cls_id, sep_id, pad_id=0,
-                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False):
+                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False, disable_retriever_dropout=False):
         super().__init__()
         self.topk = topk
         self.language_model = T5Model(cfg, t5_vocab_size, 2, checkpoint_activations)
@@ -120,13 +120,16 @@ class EMDR2Model(torch.nn.Module):
         self.seq_length, self.seq_length_ret = seq_length, seq_length_ret
         self.cls_id, self.sep_id, self.pad_id = cls_id, sep_id, pad_id
         self.update_retriever, self.retriever_score_scaling = update_retriever, retriever_score_scaling
+        self.disable_retriever_dropout = disable_retriever_dropout                  # --disable-retriever-dropout (arguments.py:558)
 
     def retriever_embedder(self, tokens, mask, types, embedder_type, disable_dropout=False):
         tower = self.retriever_model.query_model if embedder_type == "query" else self.retriever_model.context_model
+        if disable_dropout:
+            tower.eval()                                                            # emdr2_model.py:69-78
         return self.retriever_model.embed_text(tower, tokens, types)
 
     def forward(self, query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5, query_ids_t5_len, dec_ids):
-        query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query")
+        query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query", self.disable_retriever_dropout)
         with torch.no_grad():                                            # emdr2_model.py:107-115 on the device
             ctx_ids, ctx_types, qext, qone, _, _ = self.evidence_retriever.get_topk_assembled(
                 query_logits.detach(), query_uid, query_ids_t5, query_ids_t5_len, self.cls_id, self.sep_id, self.pad_id)
@@ -135,7 +138,8 @@ class EMDR2Model(torch.nn.Module):
     def forward_assembled(self, query_logits, ctx_ids, ctx_types, qext, qone, dec_ids):
         B, Kk = ctx_ids.shape[:2]
         H = self.hidden_size
-        ctx_logits = self.retriever_embedder(ctx_ids.reshape(B * Kk, -1), None, ctx_types.reshape(B * Kk, -1), "context").reshape(B, Kk, H)
+        ctx_logits = self.retriever_embedder(ctx_ids.reshape(B * Kk, -1), None, ctx_types.reshape(B * Kk, -1), "context",
+                                             self.disable_retriever_dropout).reshape(B, Kk, H)
         # fresh retriever scores (emdr2_model.py:134-145): 2*B*K*H flop, negligible; kept in torch fp32 on purpose
         sim = torch.bmm(query_logits.unsqueeze(1).float(), ctx_logits.float().transpose(1, 2))
         if self.retriever_score_scaling:
@@ -150,8 +154,12 @@ class EMDR2Model(torch.nn.Module):
         if self.training and self.update_retriever:
             with torch.no_grad():                                                             # :185-210
                 dec_rep = torch.repeat_interleave(dec_ids, Kk, dim=0)
-                enc1 = self.language_model.encode(qone)
-                one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
+                K.DROPOUT.pass_id = 1                                                         # a second, independent draw of every dropout site
+                try:
+                    enc1 = self.language_model.encode(qone)
+                    one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
+                finally:
+                    K.DROPOUT.pass_id = 0
         return lm_logits, topk_log_probs, one
 
     def state_dict_for_save_checkpoint(self):

@@ -28,12 +28,36 @@ def _check_bf16(*ts):
             raise TypeError("expected a CUDA bfloat16 tensor")
 
 
+# ---- dropout seeds -----------------------------------------------------------------------------------------------------------
+class _DropoutState(object):
+    """Every dropout site (a module instance x a role) owns a static site id; the seed a kernel gets is a hash of
+    (base seed, optimizer step, pass id, site id).  It is a pure function of those four, so a layer recomputed by
+    --checkpoint-activations regenerates exactly the bits of its first forward, and a backward regenerates the forward's mask instead of
+    storing it.  `pass_id` separates the several forward passes one training step makes through the same layers (reader over K documents
+    vs. the one-context pass).  Like the reference (megatron/initialize.py:_set_random_seed) all data-parallel ranks use the same seed."""
+
+    def __init__(self):
+        self.base_seed, self.step, self.pass_id, self._sites = 1234, 0, 0, 0
+
+    def new_site(self):
+        self._sites += 1
+        return self._sites
+
+    def seed(self, site):
+        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77 + self.pass_id * 0xC2B2AE3D + site * 0x27D4EB2F) & 0xFFFFFFFF
+        x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
+        return x
+
+
+DROPOUT = _DropoutState()
+
+
 # ---- raw kernels --------------------------------------------------------------------------------------------------------
 def gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None,
-            gelu=False, pre_act=None, residual=None, split_k=1):
+            gelu=False, pre_act=None, residual=None, split_k=1, drop_p=0.0, seed=0):
     _native.check(_lib().emdr2_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, batch1, sA1, sB1, sC1, batch2, sA2,
                                             sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual),
-                                            int(C.dtype == torch.float32), split_k, _sp()), "gemm_nt_bf16")
+                                            int(C.dtype == torch.float32), split_k, float(drop_p), int(seed), _sp()), "gemm_nt_bf16")
     return C
 
 
@@ -130,7 +154,7 @@ class LinearFn(torch.autograd.Function):
     p = 0: mpu/layers.py:255,353, transformer.py:94-108,397-407).  W, b are fp32 masters; GEMMs run on bf16 copies."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu, residual, row_perm=None):
+    def forward(ctx, x, weight, bias, gelu, residual, row_perm=None, drop_p=0.0, seed=0):
         _check_bf16(x, residual)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -145,8 +169,9 @@ class LinearFn(torch.autograd.Function):
         bb = None
         if bias is not None:
             bb = bias.detach() if row_perm is None else WEIGHTS.get(bias, "perm", lambda: bias.detach()[row_perm].contiguous())
-        gemm_nt(x2, K, wb, K, y, N, M, N, K, bias=bb, gelu=gelu, pre_act=pre, residual=res2)
+        gemm_nt(x2, K, wb, K, y, N, M, N, K, bias=bb, gelu=gelu, pre_act=pre, residual=res2, drop_p=drop_p, seed=seed)
         ctx.save_for_backward(x2, pre)
+        ctx.drop_p, ctx.seed = drop_p, seed
         ctx.weight, ctx.bias, ctx.gelu, ctx.has_res, ctx.shp, ctx.row_perm = weight, bias, gelu, residual is not None, shp, row_perm
         return y.reshape(shp[:-1] + (N,))
 
@@ -160,6 +185,10 @@ class LinearFn(torch.autograd.Function):
         if not dy2.is_contiguous():
             dy2 = dy2.contiguous()
         dres = dy if ctx.has_res else None
+        if ctx.drop_p > 0.0:                                                              # the epilogue's dropout mask, regenerated
+            dmask = torch.empty_like(dy2)
+            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), ctx.drop_p, ctx.seed, _sp()), "dropout")
+            dy2 = dmask
         if ctx.gelu:
             dpre = torch.empty_like(dy2)
             _native.check(_lib().emdr2_gelu_bwd(pre.data_ptr(), dy2.data_ptr(), dpre.data_ptr(), dy2.numel(), _sp()), "gelu_bwd")
@@ -182,11 +211,11 @@ class LinearFn(torch.autograd.Function):
             _accum_grad(weight, dW)
             if bias is not None:
                 _accum_grad(bias, db)
-        return dx, None, None, None, dres, None
+        return dx, None, None, None, dres, None, None, None
 
 
-def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None):
-    return LinearFn.apply(x, weight, bias, gelu, residual, row_perm)
+def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None, drop_p=0.0, seed=0):
+    return LinearFn.apply(x, weight, bias, gelu, residual, row_perm, drop_p, seed)
 
 
 class LayerNormFn(torch.autograd.Function):
@@ -226,33 +255,41 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 
 class AttentionCoreFn(torch.autograd.Function):
-    """softmax(mask(Q K^T / sqrt(hn))) V for all heads (transformer.py:283-381).  q [b, sq, np, hn], k, v [b, sk, np, hn] are strided
-    views (last dim contiguous) into the projection outputs; masks come from token ids (pad id 0) + optional history mask."""
+    """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).  q [b, sq, np, hn], k, v [b, sk, np, hn] are
+    strided views (last dim contiguous) into the projection outputs; masks come from token ids (pad id 0) + optional history mask.
+    Forward: the fused kernel (attention.hip) when hn == 64 and sk % 64 == 0, else QK^T GEMM + softmax kernel + PV GEMM.  Only the row
+    statistics (max, sum-exp) are kept; the backward rebuilds the probabilities from them in both orientations."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ids_q, ids_k, causal):
+    def forward(ctx, q, k, v, ids_q, ids_k, causal, drop_p=0.0, seed=0):
         _check_bf16(q, k, v)
         b, sq, heads, hn = q.shape
         sk = k.shape[1]
         dev = q.device
         scale = 1.0 / math.sqrt(hn)
-        S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
-        gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
-                sq * sk, alpha=scale)
         m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
-        _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal), m.data_ptr(),
-                                                    l.data_ptr(), _sp()), "softmax_fwd")
         vT = head_transpose(v, b, sk, heads, hn)
         ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
-        gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
-        ctx.save_for_backward(q, k, v, S, m, l, ids_q, ids_k)
-        ctx.causal = causal
+        if hn == 64 and sk % 64 == 0 and sk <= 65536:
+            _native.check(_lib().emdr2_attention_fwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
+                                                     k.stride(2), vT.data_ptr(), ctxo.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq,
+                                                     sk, hn, int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), _sp()),
+                          "attention_fwd")
+        else:
+            S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
+            gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2),
+                    k.stride(2), sq * sk, alpha=scale)
+            _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal),
+                                                        m.data_ptr(), l.data_ptr(), float(drop_p), int(seed), _sp()), "softmax_fwd")
+            gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
+        ctx.save_for_backward(q, k, v, m, l, ids_q, ids_k)
+        ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
         return ctxo
 
     @staticmethod
     def backward(ctx, dctx):
-        q, k, v, P, m, l, ids_q, ids_k = ctx.saved_tensors
+        q, k, v, m, l, ids_q, ids_k = ctx.saved_tensors
         b, sq, heads, hn = q.shape
         sk = k.shape[1]
         dev = q.device
@@ -261,47 +298,53 @@ class AttentionCoreFn(torch.autograd.Function):
         dctx = dctx.contiguous()
         H = heads * hn
         lib = _lib()
-        # dP = dctx V^T, dS = P (dP - D)
+        # main orientation: S = scale Q K^T (recomputed), dP = dctx V^T, dS = P (dP_eff - D) with P rebuilt from (m, l)
+        S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
+        gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
+                sq * sk, alpha=scale)
         dP = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(dctx, H, v, v.stride(1), dP, sk, sq, sk, hn, b, sq * H, v.stride(0), heads * sq * sk, heads, hn, v.stride(2), sq * sk)
         D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
-        _native.check(lib.emdr2_softmax_mask_bwd(P.data_ptr(), dP.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, causal,
-                                                 D.data_ptr(), _sp()), "softmax_bwd")
+        _native.check(lib.emdr2_softmax_mask_bwd(S.data_ptr(), dP.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(), b,
+                                                 heads, sq, sk, causal, ctx.drop_p, ctx.seed, D.data_ptr(), _sp()), "softmax_bwd")
+        del S
         dq = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
         kT = head_transpose(k, b, sk, heads, hn)
         gemm_nt(dP, sk, kT, sk, dq, H, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * H, heads, sq * sk, hn * sk, hn, alpha=scale)
-        # transposed branch: S^T, dP^T recomputed in the orientation dK / dV need (no [sq, sk] transposes)
+        del dP
+        # transposed orientation: S^T, dP^T recomputed in the layout dK / dV need (no [sq, sk] transposes)
         St = torch.empty((b, heads, sk, sq), dtype=BF16, device=dev)
         gemm_nt(k, k.stride(1), q, q.stride(1), St, sq, sk, sq, hn, b, k.stride(0), q.stride(0), heads * sk * sq, heads, k.stride(2), q.stride(2),
                 sk * sq, alpha=scale)
         dPt = torch.empty_like(St)
         gemm_nt(v, v.stride(1), dctx, H, dPt, sq, sk, sq, hn, b, v.stride(0), sq * H, heads * sk * sq, heads, v.stride(2), hn, sk * sq)
         _native.check(lib.emdr2_softmax_mask_t(St.data_ptr(), dPt.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(),
-                                               D.data_ptr(), b, heads, sq, sk, causal, _sp()), "softmax_t")
+                                               D.data_ptr(), b, heads, sq, sk, causal, ctx.drop_p, ctx.seed, _sp()), "softmax_t")
         qT = head_transpose(q, b, sq, heads, hn)
         dk = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
         gemm_nt(dPt, sq, qT, sq, dk, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn, alpha=scale)
         dctxT = head_transpose(dctx.view(b, sq, heads, hn), b, sq, heads, hn)
         dv = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
         gemm_nt(St, sq, dctxT, sq, dv, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn)
-        return dq, dk, dv, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
-def attention_core(q, k, v, ids_q, ids_k, causal=False):
-    return AttentionCoreFn.apply(q, k, v, ids_q, ids_k, causal)
+def attention_core(q, k, v, ids_q, ids_k, causal=False, drop_p=0.0, seed=0):
+    return AttentionCoreFn.apply(q, k, v, ids_q, ids_k, causal, drop_p, seed)
 
 
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, types, W, P, T):
+    def forward(ctx, ids, types, W, P, T, drop_p=0.0, seed=0):
         b, s = ids.shape
         H = W.shape[1]
         out = torch.empty((b, s, H), dtype=BF16, device=ids.device)
         ids = ids.contiguous()
         types = types.contiguous() if types is not None else None
         _native.check(_lib().emdr2_embedding_fwd(ids.data_ptr(), _ptr(types), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
-                                                 w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), b * s, s, H, _sp()), "embedding_fwd")
-        ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T = ids, types, W, P, T
+                                                 w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), b * s, s, H, float(drop_p),
+                                                 int(seed), _sp()), "embedding_fwd")
+        ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T, ctx.drop_p, ctx.seed = ids, types, W, P, T, drop_p, seed
         return out
 
     @staticmethod
@@ -313,16 +356,16 @@ class EmbeddingFn(torch.autograd.Function):
         dW, dP = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(P, dtype=torch.float32)
         dT = torch.zeros_like(T, dtype=torch.float32) if types is not None else None
         _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
-                                                 _sp()), "embedding_bwd")
+                                                 float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
         _accum_grad(W, dW)
         _accum_grad(P, dP)
         if dT is not None:
             _accum_grad(T, dT)
-        return None, None, None, None, None
+        return None, None, None, None, None, None, None
 
 
-def embedding(ids, types, W, P, T):
-    return EmbeddingFn.apply(ids, types, W, P, T)
+def embedding(ids, types, W, P, T, drop_p=0.0, seed=0):
+    return EmbeddingFn.apply(ids, types, W, P, T, drop_p, seed)
 
 
 class LseGatherFn(torch.autograd.Function):

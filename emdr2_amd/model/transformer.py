@@ -9,8 +9,9 @@ tree and parameter names so its checkpoints load unchanged (`state_dict` keys id
 Differences that are deliberate: activations are [b, s, h] bf16 (the reference: [s, b, h] fp16); parameters are fp32 masters whose
 bf16 working copies are refreshed after each optimizer step; attention masks are not materialised (the kernels derive them from token
 ids: pad id 0, plus the history mask for decoder self-attention) - `forward` therefore takes token ids where the reference takes masks;
-tensor model parallelism is not built (asserted 1 in the reference, dualencoder_model.py:15).  Dropout probabilities must be 0 in this
-round (the reference's parity configuration); see DESIGN.md.
+tensor model parallelism is not built (asserted 1 in the reference, dualencoder_model.py:15).  Dropout (embedding, attention probabilities,
+bias-dropout-add; active only in `.train()` mode) is counter-based inside the kernels (csrc/rng.h, kernels.DROPOUT): masks are regenerated
+in the backward / activation recompute, never stored.
 """
 import math
 
@@ -28,8 +29,9 @@ class Config(object):
 
     def __init__(self, num_layers=12, hidden_size=768, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512,
                  layernorm_epsilon=1e-5, init_method_std=0.02, hidden_dropout=0.0, attention_dropout=0.0):
-        if hidden_dropout or attention_dropout:
-            raise NotImplementedError("dropout > 0 is not built yet (parity runs use 0, SURVEY.md section 7)")
+        if not (0.0 <= hidden_dropout < 1.0 and 0.0 <= attention_dropout < 1.0):
+            raise ValueError("dropout probabilities must be in [0, 1)")
+        self.hidden_dropout, self.attention_dropout = float(hidden_dropout), float(attention_dropout)
         self.num_layers, self.hidden_size, self.num_attention_heads = num_layers, hidden_size, num_attention_heads
         self.ffn_hidden_size, self.max_position_embeddings = ffn_hidden_size, max_position_embeddings
         self.layernorm_epsilon, self.init_method_std = layernorm_epsilon, init_method_std
@@ -66,10 +68,13 @@ class ParallelMLP(torch.nn.Module):
         super().__init__()
         self.dense_h_to_4h = Linear(cfg.hidden_size, cfg.ffn_hidden_size, cfg.init_method_std)
         self.dense_4h_to_h = Linear(cfg.ffn_hidden_size, cfg.hidden_size, out_std)
+        self.hidden_dropout, self._site = cfg.hidden_dropout, K.DROPOUT.new_site()
 
     def forward(self, x, residual):
         inter = K.linear(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, gelu=True)          # bias + exact-erf GELU in the epilogue
-        return K.linear(inter, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, residual=residual)  # bias + residual in the epilogue
+        p = self.hidden_dropout if self.training else 0.0
+        return K.linear(inter, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, residual=residual,  # bias-dropout-add in the epilogue
+                        drop_p=p, seed=K.DROPOUT.seed(self._site) if p else 0)
 
 
 class ParallelAttention(torch.nn.Module):
@@ -85,6 +90,8 @@ class ParallelAttention(torch.nn.Module):
             self.key_value = Linear(h, 2 * h, cfg.init_method_std)
             self.register_buffer("_perm", _deinterleave_perm(self.heads, self.hn, 2, "cuda"), persistent=False)
         self.dense = Linear(h, h, out_std)
+        self.hidden_dropout, self.attention_dropout = cfg.hidden_dropout, cfg.attention_dropout
+        self._site_attn, self._site_out = K.DROPOUT.new_site(), K.DROPOUT.new_site()
 
     def forward(self, x, ids_q, ids_k, causal, residual, encoder_output=None):
         b, sq, h = x.shape
@@ -96,8 +103,10 @@ class ParallelAttention(torch.nn.Module):
             kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
             k, v = kv[:, :, 0], kv[:, :, 1]
             q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
-        ctx = K.attention_core(q, k, v, ids_q, ids_k, causal).view(b, sq, h)
-        return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual)
+        pa = self.attention_dropout if self.training else 0.0
+        ph = self.hidden_dropout if self.training else 0.0
+        ctx = K.attention_core(q, k, v, ids_q, ids_k, causal, drop_p=pa, seed=K.DROPOUT.seed(self._site_attn) if pa else 0).view(b, sq, h)
+        return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
 
 class ParallelTransformerLayer(torch.nn.Module):
@@ -150,10 +159,13 @@ class Embedding(torch.nn.Module):
         self.word_embeddings = _Table(vocab_size, cfg.hidden_size, cfg.init_method_std)
         self.position_embeddings = _Table(cfg.max_position_embeddings, cfg.hidden_size, cfg.init_method_std)
         self.tokentype_embeddings = _Table(num_tokentypes, cfg.hidden_size, cfg.init_method_std) if num_tokentypes > 0 else None
+        self.embedding_dropout, self._site = cfg.hidden_dropout, K.DROPOUT.new_site()          # language_model.py:289: hidden_dropout
 
     def forward(self, ids, tokentype_ids=None):
         T = self.tokentype_embeddings.weight if tokentype_ids is not None else None
-        return K.embedding(ids, tokentype_ids, self.word_embeddings.weight, self.position_embeddings.weight, T)
+        p = self.embedding_dropout if self.training else 0.0
+        return K.embedding(ids, tokentype_ids, self.word_embeddings.weight, self.position_embeddings.weight, T, drop_p=p,
+                           seed=K.DROPOUT.seed(self._site) if p else 0)
 
 
 class TransformerLanguageModel(torch.nn.Module):

@@ -71,6 +71,7 @@ class FusedAdam(object):
                                                   self.clip_grad, sp), "adam_step")
         from emdr2_amd.model import kernels
         kernels.WEIGHTS.invalidate()      # masters were written through raw pointers: bf16 working copies are rebuilt lazily
+        kernels.DROPOUT.step = self.step_count   # next iteration draws fresh dropout masks
         return gsq
 
 

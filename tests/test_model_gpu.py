@@ -157,3 +157,42 @@ def test_adam_step_matches_torch_adamw_with_clipping():
         ropt.step(); opt.step()
     for p, r in zip(ps, ref):
         assert torch.allclose(p, r, rtol=1e-5, atol=1e-6)
+
+
+def test_dropout_is_reproduced_by_activation_recompute_and_changes_per_step():
+    """hidden / attention / embedding dropout at the reference's 0.1: a checkpointed (recomputed) layer must see the mask of its first
+    forward (gradients equal to the non-checkpointed run), eval() disables it, and the optimizer step advances the stream."""
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.model.transformer import Config, T5Model
+
+    def build(ckpt):
+        torch.manual_seed(0)
+        K.DROPOUT._sites = 0
+        cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05,
+                     hidden_dropout=0.1, attention_dropout=0.1)
+        return T5Model(cfg, 512, checkpoint_activations=ckpt)
+
+    rng = np.random.default_rng(3)
+    enc_ids, dec_ids = _ids(rng, (8, 64), 512).cuda(), _ids(rng, (8, 32), 512).cuda()
+    grads, outs = [], []
+    for ckpt in (False, True):
+        m = build(ckpt)
+        m.train()
+        K.DROPOUT.step = 5
+        logits, _ = m(enc_ids, dec_ids)
+        logits.float().square().mean().backward()
+        outs.append(logits.detach().float())
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert torch.equal(outs[0], outs[1])
+    for k in grads[0]:
+        assert _rel(grads[1][k], grads[0][k]) < 1e-3, k                  # same masks; atomics reorder fp32 sums
+    m.eval()
+    e1, _ = m(enc_ids, dec_ids)
+    e2, _ = m(enc_ids, dec_ids)
+    assert torch.equal(e1, e2) and not torch.equal(e1.float(), outs[1])
+    m.train()
+    K.DROPOUT.step = 6
+    t2, _ = m(enc_ids, dec_ids)
+    assert not torch.equal(t2.float(), outs[1])
+    # the expected value is preserved: train-mode logits scatter around the eval-mode ones
+    assert _rel(t2.float(), e1.float()) < 1.0

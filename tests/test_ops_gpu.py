@@ -24,7 +24,7 @@ def _gemm(A, B, bias=None, gelu=False, residual=None, alpha=1.0, out_f32=False, 
     nat.check(lib.emdr2_gemm_nt_bf16(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, batch, M * K, (N * K if B.dim() > 2 else 0), M * N,
                                      1, 0, 0, 0, alpha, bias.data_ptr() if bias is not None else None, int(gelu),
                                      pre.data_ptr() if pre is not None else None, residual.data_ptr() if residual is not None else None,
-                                     int(out_f32), 1, nat.stream_ptr()), "gemm")
+                                     int(out_f32), 1, 0.0, 0, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     return (C, pre) if want_pre else C
 
@@ -72,7 +72,7 @@ def test_gemm_batched_two_levels_strided():
     q, k = qkv[:, :, 0], qkv[:, :, 1]
     ld = 3 * heads * hn
     nat.check(lib.emdr2_gemm_nt_bf16(q.data_ptr(), ld, k.data_ptr(), ld, scores.data_ptr(), s, s, s, hn, b, s * ld, s * ld, heads * s * s,
-                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, 1, nat.stream_ptr()), "gemm")
+                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, 1, 0.0, 0, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     ref = torch.einsum("bqnd,bknd->bnqk", q.float(), k.float()) * 0.125
     assert torch.allclose(scores.float(), ref, rtol=2e-2, atol=5e-2)
@@ -101,3 +101,125 @@ def test_weight_gradient_gemm_split_k():
     torch.cuda.synchronize()
     ref = dyT.float() @ xT.float().T
     assert torch.allclose(dW, ref, rtol=2e-3, atol=0.5)
+
+
+# ---- fused attention + dropout ------------------------------------------------------------------------------------------
+def _dropout_mask(shape, p, seed):
+    """The multiplicative mask (0 or 1/(1-p)) of a dropout site, through the same kernel the backward uses."""
+    nat, lib = _lib()
+    ones = torch.ones(shape, dtype=torch.bfloat16, device="cuda")
+    out = torch.empty_like(ones)
+    nat.check(lib.emdr2_dropout(ones.data_ptr(), out.data_ptr(), ones.numel(), p, seed, nat.stream_ptr()), "dropout")
+    torch.cuda.synchronize()
+    return out.float()
+
+
+def _attention_reference(q, k, v, ids_q, ids_k, causal, mask=None):
+    """fp32 torch restatement with the reference's semantics (transformer.py:283-381): masked scores replaced by -10000."""
+    hn = q.shape[-1]
+    s = torch.einsum("bqnd,bknd->bnqk", q, k) / hn ** 0.5
+    m = (ids_q[:, None, :, None] == 0) | (ids_k[:, None, None, :] == 0)
+    if causal:
+        sq, sk = q.shape[1], k.shape[1]
+        m = m | (torch.arange(sk, device=q.device)[None, None, None, :] > torch.arange(sq, device=q.device)[None, None, :, None])
+    p = torch.softmax(s.masked_fill(m, -10000.0), dim=-1)
+    if mask is not None:
+        p = p * mask
+    return torch.einsum("bnqk,bknd->bqnd", p, v)
+
+
+def _attention_case(b, heads, sq, sk, causal, drop_p, seed, gen_seed):
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(gen_seed)
+    hn = 64
+    q = torch.randn((b, sq, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    kv = torch.randn((b, sk, 2, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    ids_q = torch.randint(1, 100, (b, sq), generator=g, device="cuda")
+    ids_k = ids_q if sq == sk else torch.randint(1, 100, (b, sk), generator=g, device="cuda")
+    for i in range(b):                                                  # ragged padding; row b-1 of ids_q fully padded exercises uniform rows
+        ids_k[i, sk - 7 * i - 3:] = 0
+        if sq != sk:
+            ids_q[i, sq - i - 1:] = 0
+    out = K.attention_core(q, kv[:, :, 0], kv[:, :, 1], ids_q, ids_k, causal, drop_p=drop_p, seed=seed)
+    w = torch.randn(out.shape, generator=g, device="cuda")
+    (out.float() * w).sum().backward()
+    mask = _dropout_mask((b, heads, sq, sk), drop_p, seed) if drop_p > 0 else None
+    qf = q.detach().float().requires_grad_(True)
+    kvf = kv.detach().float().requires_grad_(True)
+    ref = _attention_reference(qf, kvf[:, :, 0], kvf[:, :, 1], ids_q, ids_k, causal, mask)
+    (ref * w).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert rel(out, ref) < 2e-2, ("out", rel(out, ref))
+    assert rel(q.grad, qf.grad) < 3e-2, ("dq", rel(q.grad, qf.grad))
+    assert rel(kv.grad, kvf.grad) < 3e-2, ("dkv", rel(kv.grad, kvf.grad))
+
+
+@pytest.mark.parametrize("b,heads,sq,sk,causal", [(3, 4, 64, 64, False), (2, 3, 512, 512, False), (2, 2, 256, 256, True), (3, 2, 32, 1024, False),
+                                                  (2, 2, 288, 320, False), (2, 2, 32, 32, True), (2, 2, 96, 96, False)])
+def test_attention_core_forward_backward_vs_torch(b, heads, sq, sk, causal):
+    """Fused kernel (sk % 64 == 0) and the GEMM + softmax composition (the rest) against fp32 torch, forward and q/k/v gradients."""
+    _attention_case(b, heads, sq, sk, causal, 0.0, 0, 100 + sq + sk)
+
+
+@pytest.mark.parametrize("sq,sk", [(128, 128), (32, 640), (96, 96), (32, 32)])
+def test_attention_dropout_mask_is_the_same_in_forward_backward_and_both_paths(sq, sk):
+    _attention_case(2, 3, sq, sk, sq == sk and sq == 32, 0.1, 0xC0FFEE + sq, 7 + sq)
+
+
+def test_dropout_statistics_and_determinism():
+    p = 0.1
+    m1 = _dropout_mask((4096, 768), p, 17)
+    keep = float((m1 != 0).float().mean())
+    n = m1.numel()
+    assert abs(keep - (1 - p)) < 5 * (p * (1 - p) / n) ** 0.5
+    vals = torch.unique(m1)
+    assert vals.numel() == 2 and float(vals[0]) == 0.0 and abs(float(vals[1]) - 1 / (1 - p)) < 1e-2
+    assert torch.equal(m1, _dropout_mask((4096, 768), p, 17))
+    m2 = _dropout_mask((4096, 768), p, 18)
+    agree = float(((m1 != 0) == (m2 != 0)).float().mean())
+    assert abs(agree - ((1 - p) ** 2 + p ** 2)) < 5e-3                  # independent streams
+    # no structure along rows / columns
+    assert float((m1 != 0).float().mean(0).std()) < 3 * (p * (1 - p) / 4096) ** 0.5 * 1.5
+    assert float((m1 != 0).float().mean(1).std()) < 3 * (p * (1 - p) / 768) ** 0.5 * 1.5
+
+
+def test_linear_bias_dropout_add_forward_and_backward():
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(9)
+    M, N, Kd, p, seed = 512, 768, 256, 0.1, 4242
+    x = (torch.randn((M, Kd), generator=g, device="cuda") * 0.5).bfloat16().requires_grad_(True)
+    res = torch.randn((M, N), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    W = torch.nn.Parameter(torch.randn((N, Kd), generator=g, device="cuda") * 0.1)
+    bias = torch.nn.Parameter(torch.randn(N, generator=g, device="cuda"))
+    y = K.linear(x, W, bias, residual=res, drop_p=p, seed=seed)
+    w = torch.randn(y.shape, generator=g, device="cuda")
+    (y.float() * w).sum().backward()
+    mask = _dropout_mask((M, N), p, seed)
+    xf, rf = x.detach().float().requires_grad_(True), res.detach().float().requires_grad_(True)
+    Wf, bf = W.detach().bfloat16().float().requires_grad_(True), bias.detach().clone().requires_grad_(True)
+    ref = (xf @ Wf.T + bf) * mask + rf
+    (ref * w).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert torch.equal((y.float() - res.float() == 0), (ref - rf == 0)) or rel(y, ref) < 2e-2
+    assert rel(y, ref) < 2e-2
+    assert rel(x.grad, xf.grad) < 3e-2 and rel(res.grad, rf.grad) < 1e-2
+    assert rel(W.grad, Wf.grad) < 3e-2 and rel(bias.grad, bf.grad) < 3e-2
+
+
+def test_embedding_dropout_forward_and_backward():
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(10)
+    b, s, H, V, p, seed = 4, 64, 128, 300, 0.1, 99
+    Wt = torch.nn.Parameter(torch.randn((V, H), generator=g, device="cuda"))
+    Pt = torch.nn.Parameter(torch.randn((s, H), generator=g, device="cuda"))
+    ids = torch.randint(0, V, (b, s), generator=g, device="cuda")
+    out = K.embedding(ids, None, Wt, Pt, None, drop_p=p, seed=seed)
+    w = torch.randn(out.shape, generator=g, device="cuda")
+    (out.float() * w).sum().backward()
+    mask = _dropout_mask((b, s, H), p, seed)
+    Wf, Pf = Wt.detach().bfloat16().float().requires_grad_(True), Pt.detach().bfloat16().float().requires_grad_(True)
+    ref = (Wf[ids] + Pf[None, :s]) * mask
+    (ref * w).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert rel(out, ref) < 1e-2
+    assert rel(Wt.grad, Wf.grad) < 2e-2 and rel(Pt.grad, Pf.grad) < 2e-2
