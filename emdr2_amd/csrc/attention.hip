@@ -19,6 +19,8 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
 
@@ -89,9 +91,16 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
+    // Softmax bookkeeping in the log2 domain: s2 = score * scale * log2(e), p = exp2(s2 - m2): one FMA + one v_exp per element.
+    // A padded query has every score replaced by -10000: per-lane (scale, offset) = (0, -10000 log2 e) does that without a select.
+    const float L2E = 1.4426950408889634f, MASKED2 = -10000.f * 1.4426950408889634f;
+    const float sc_q = qpad ? 0.f : p.scale * L2E, c_q = qpad ? MASKED2 : 0.f;
+    const bool any_qpad = __builtin_amdgcn_ballot_w64(qpad) != 0ull;
     float mrun = -3.0e38f, lrun = 0.f;
-    const float inv_keep = p.drop_p > 0.f ? 1.f / (1.f - p.drop_p) : 1.f;
-    const unsigned long long rowbase = (((unsigned long long)b * p.heads + n) * p.sq + (unsigned)qc) * (unsigned long long)p.sk;
+    const bool drop = p.drop_p > 0.f;
+    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const uint32_t thr = emdr2_drop_thr(p.drop_p);
+    const uint32_t rh = emdr2_row_hash(p.seed, ((unsigned long long)b * p.heads + n) * p.sq + (unsigned)qc);
 
     issue(0, 0);
     for (int blk = 0; blk < nblk; ++blk) {
@@ -100,6 +109,12 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
         __syncthreads();                                                          // ... from every wave; everyone is done with the other stage
         if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);
         const unsigned long long kmask = kmask_s[blk];
+        const int key0 = blk * KB;
+        // A block whose keys are all masked for every query of this wave contributes exp(-10000 - m) == 0 exactly once each query has
+        // seen a real key (m > -7000): skip it.  Rows that are masked everywhere (padded queries) need every block, hence any_qpad.
+        if ((kmask == 0ull || (p.causal && key0 > q0 + QW - 1)) && !any_qpad && blk > 0 &&
+            __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
+            continue;
         const char *sb = smem + stage * 16384;
 
         // ---- S^T = K Q^T : 2 key sub-blocks x 4 k-steps --------------------------------------------------------------
@@ -116,54 +131,77 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
             }
         }
         // ---- mask, online softmax (this lane: one query, 32 of the 64 keys; its half-wave partner holds the other 32) ----
-        float bmax = -3.0e38f;
+        const bool need_mask = kmask != ~0ull || (p.causal && key0 + KB - 1 > q0);   // wave-uniform
+        float bmax, bsum = 0.f;
+        if (!need_mask) {
+            float mx = sacc[0][0];
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;       // key inside the block
-                const int key = blk * KB + kl;
-                const bool masked = qpad || !((kmask >> kl) & 1ull) || (p.causal && key > qi);
-                const float s = masked ? -10000.f : sacc[j][r] * p.scale;
-                sacc[j][r] = s;
-                bmax = fmaxf(bmax, s);
-            }
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
+            bmax = fmaf(mx, sc_q, c_q);                                          // sc_q >= 0: max commutes with the affine map
+        } else {
+            bmax = -3.0e38f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // key inside the block
+                    const bool masked = !((kmask >> kl) & 1ull) || (p.causal && key0 + kl > qi);
+                    const float s2 = masked ? MASKED2 : fmaf(sacc[j][r], sc_q, c_q);
+                    sacc[j][r] = s2;
+                    bmax = fmaxf(bmax, s2);
+                }
+        }
         bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
         const float mnew = fmaxf(mrun, bmax);
-        const float alpha = __expf(mrun - mnew);
-        float bsum = 0.f;
+        if (!need_mask) {
+            const float off = c_q - mnew;
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __expf(sacc[j][r] - mnew);
-                bsum += e;
-                float pd = e;
-                if (p.drop_p > 0.f) {
-                    const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    pd = emdr2_uniform01(p.seed, rowbase + (unsigned)(blk * KB + kl)) >= p.drop_p ? e * inv_keep : 0.f;
-                }
-                sacc[j][r] = pd;
-            }
+                for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc_q, off)); sacc[j][r] = e; bsum += e; }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[j][r] - mnew); sacc[j][r] = e; bsum += e; }
+        }
         bsum += __shfl_xor(bsum, 32);
+        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
         lrun = lrun * alpha + bsum;
+        if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {                 // the running max moved for some query of this wave
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+        }
         mrun = mnew;
+        if (drop) {                                                               // attention dropout after the normaliser (l is un-dropped)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < 2; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t col = (uint32_t)(key0 + j * 32 + 8 * g + 4 * hi);
+                    const uint32_t b0 = emdr2_pair_bits(rh, col), b1 = emdr2_pair_bits(rh, col + 2);
+                    sacc[j][4 * g] = (b0 & 0xffffu) >= thr ? sacc[j][4 * g] * ik : 0.f;
+                    sacc[j][4 * g + 1] = (b0 >> 16) >= thr ? sacc[j][4 * g + 1] * ik : 0.f;
+                    sacc[j][4 * g + 2] = (b1 & 0xffffu) >= thr ? sacc[j][4 * g + 2] * ik : 0.f;
+                    sacc[j][4 * g + 3] = (b1 >> 16) >= thr ? sacc[j][4 * g + 3] * ik : 0.f;
+                }
+        }
 
         // ---- O^T += V^T P^T : 2 d sub-blocks x 4 k-steps (16 keys each: registers 8u..8u+7 of sub-block u>>1) -------------
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            bf16x8 pf;
             uint32_t pw[4];
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int r0 = (u & 1) * 8 + 2 * w;
-                pw[w] = (uint32_t)f2bf(sacc[u >> 1][r0]) | ((uint32_t)f2bf(sacc[u >> 1][r0 + 1]) << 16);
+                const floatx2 pr = {sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]};
+                pw[w] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
             }
-            pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
             // the 8 keys of this lane in k-step u: base + {0,1,2,3, 8,9,10,11} + 4*half, base = (u>>1)*32 + (u&1)*16
             const int kb0 = (u >> 1) * 32 + (u & 1) * 16 + 4 * hi;
 #pragma unroll
@@ -194,7 +232,7 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
             }
         if (hi == 0 && p.m) {
             const long long si = ((long long)b * p.heads + n) * p.sq + qi;
-            p.m[si] = mrun; p.l[si] = lrun;
+            p.m[si] = mrun * 0.6931471805599453f; p.l[si] = lrun;        // back to natural-log units
         }
     }
 }

@@ -171,7 +171,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_kernel(uint16_t *s, const lon
     for (int k = lane; k < sk; k += 64) {
         const bool masked = qpad || kid[k] == 0 || (causal && k > q);
         float pv = __expf((masked ? -10000.f : bf2f(sr[k])) - m) * inv;
-        if (drop_p > 0.f) pv = emdr2_keep(seed, (unsigned long long)row * sk + k, drop_p) ? pv / (1.f - drop_p) : 0.f;
+        if (drop_p > 0.f) pv = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)row), (uint32_t)k, emdr2_drop_thr(drop_p)) ? pv * emdr2_keep_scale(drop_p) : 0.f;
         sr[k] = f2bf(pv);
     }
     if (lane == 0 && mstat) { mstat[row] = m; lstat[row] = l; }
@@ -217,7 +217,8 @@ __global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const
         }
     l = wave_sum(l);
     const float inv = 1.f / l;
-    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
+    const uint32_t rh = emdr2_row_hash(seed, (unsigned long long)row), thr = emdr2_drop_thr(drop_p);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k0 = (i * 64 + lane) * 8;
@@ -225,7 +226,7 @@ __global__ void __launch_bounds__(256) softmax_fwd_reg_kernel(uint16_t *s, const
             uint32_t w[4];
             if (drop_p > 0.f) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) v[i][j] = emdr2_keep(seed, (unsigned long long)row * sk + k0 + j, drop_p) ? v[i][j] * ik : 0.f;
+                for (int j = 0; j < 8; ++j) v[i][j] = emdr2_keep(rh, (uint32_t)(k0 + j), thr) ? v[i][j] * ik : 0.f;
             }
 #pragma unroll
             for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f2bf(v[i][2 * j] * inv) | ((uint32_t)f2bf(v[i][2 * j + 1] * inv) << 16);
@@ -252,7 +253,8 @@ __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p,
     float pv[NV][8], gv[NV][8];
     float d = 0.f;
     const float ms = mstat ? mstat[row] : 0.f, il = mstat ? 1.f / lstat[row] : 1.f;
-    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
+    const uint32_t rh = emdr2_row_hash(seed, (unsigned long long)row), thr = emdr2_drop_thr(drop_p);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int k0 = (i * 64 + lane) * 8;
@@ -268,7 +270,7 @@ __global__ void __launch_bounds__(256) softmax_bwd_reg_kernel(const uint16_t *p,
                     const bool masked = qpad || kid[k] == 0 || (causal && k > q);
                     pv[i][j] = __expf((masked ? -10000.f : pv[i][j]) - ms) * il;
                 }
-                if (drop_p > 0.f) gv[i][j] = emdr2_keep(seed, (unsigned long long)row * sk + k0 + j, drop_p) ? gv[i][j] * ik : 0.f;
+                if (drop_p > 0.f) gv[i][j] = emdr2_keep(rh, (uint32_t)(k0 + j), thr) ? gv[i][j] * ik : 0.f;
                 d += pv[i][j] * gv[i][j];
             }
         }
@@ -312,9 +314,10 @@ __global__ void __launch_bounds__(256) softmax_bwd_kernel(const uint16_t *p, uin
     uint16_t *dr = dp + row * sk;
     float d = 0.f;
     const float ms = mstat ? mstat[row] : 0.f, il = mstat ? 1.f / lstat[row] : 1.f;
-    const float ik = drop_p > 0.f ? 1.f / (1.f - drop_p) : 1.f;
+    const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
+    const uint32_t rh = emdr2_row_hash(seed, (unsigned long long)row), thr = emdr2_drop_thr(drop_p);
     auto prob = [&](int k, bool masked) { return mstat ? __expf((masked ? -10000.f : bf2f(pr[k])) - ms) * il : bf2f(pr[k]); };
-    auto grad = [&](int k) { const float g = bf2f(dr[k]); return drop_p > 0.f ? (emdr2_keep(seed, (unsigned long long)row * sk + k, drop_p) ? g * ik : 0.f) : g; };
+    auto grad = [&](int k) { const float g = bf2f(dr[k]); return drop_p > 0.f ? (emdr2_keep(rh, (uint32_t)k, thr) ? g * ik : 0.f) : g; };
     for (int k = lane; k < sk; k += 64) d += prob(k, qpad || kid[k] == 0 || (causal && k > q)) * grad(k);
     d = wave_sum(d);
     for (int k = lane; k < sk; k += 64) {
@@ -343,8 +346,8 @@ __global__ void __launch_bounds__(256) softmax_t_kernel(uint16_t *st, uint16_t *
     const float pt = __expf((masked ? -10000.f : bf2f(st[i])) - mstat[srow]) / lstat[srow];
     float g = bf2f(dpt[i]), pd = pt;
     if (drop_p > 0.f) {
-        const bool keep = emdr2_keep(seed, (unsigned long long)srow * sk + k, drop_p);
-        const float ik = 1.f / (1.f - drop_p);
+        const bool keep = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)srow), (uint32_t)k, emdr2_drop_thr(drop_p));
+        const float ik = emdr2_keep_scale(drop_p);
         g = keep ? g * ik : 0.f;
         pd = keep ? pt * ik : 0.f;                                        // dropped probabilities (what multiplied V in the forward) for dV
     }
@@ -384,7 +387,7 @@ __global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = bf2f(W[id * H + i]) + bf2f(P[pos * H + i]);
         if (types) v += bf2f(T[ty * H + i]);
-        if (drop_p > 0.f) v = emdr2_keep(seed, (unsigned long long)(t * H + i), drop_p) ? v / (1.f - drop_p) : 0.f;
+        if (drop_p > 0.f) v = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)t), (uint32_t)i, emdr2_drop_thr(drop_p)) ? v * emdr2_keep_scale(drop_p) : 0.f;
         out[t * H + i] = f2bf(v);
     }
 }
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids
     const long long ty = types ? types[t] : 0;
     for (int i = threadIdx.x; i < H; i += 256) {
         float g = bf2f(dout[t * H + i]);
-        if (drop_p > 0.f) g = emdr2_keep(seed, (unsigned long long)(t * H + i), drop_p) ? g / (1.f - drop_p) : 0.f;
+        if (drop_p > 0.f) g = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)t), (uint32_t)i, emdr2_drop_thr(drop_p)) ? g * emdr2_keep_scale(drop_p) : 0.f;
         atomicAdd(&dW[id * H + i], g);
         atomicAdd(&dP[pos * H + i], g);
         if (types) atomicAdd(&dT[ty * H + i], g);
@@ -405,18 +408,20 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids
 }
 
 // ---- dropout mask of a site re-applied to a contiguous bf16 tensor (backward of the fused bias-dropout-add epilogue) --------------
-__global__ void __launch_bounds__(256) dropout_kernel(const uint16_t *x, uint16_t *out, long long n, float drop_p, uint32_t seed)
+__global__ void __launch_bounds__(256) dropout_kernel(const uint16_t *x, uint16_t *out, long long n, int cols, float drop_p, uint32_t seed)
 {
-    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;
+    const long long i = ((long long)blockIdx.x * 256 + threadIdx.x) * 8;     // cols % 8 == 0: the 8 elements share a row
     if (i >= n) return;
-    const float ik = 1.f / (1.f - drop_p);
+    const float ik = emdr2_keep_scale(drop_p);
+    const uint32_t thr = emdr2_drop_thr(drop_p), rh = emdr2_row_hash(seed, (unsigned long long)(i / cols)), c0 = (uint32_t)(i % cols);
     const uint4 a = *(const uint4 *)(x + i);
     const uint32_t aw[4] = {a.x, a.y, a.z, a.w};
     uint32_t w[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const float lo = emdr2_keep(seed, (unsigned long long)(i + 2 * j), drop_p) ? bf2f((uint16_t)(aw[j] & 0xffff)) * ik : 0.f;
-        const float hi = emdr2_keep(seed, (unsigned long long)(i + 2 * j + 1), drop_p) ? bf2f((uint16_t)(aw[j] >> 16)) * ik : 0.f;
+        const uint32_t b = emdr2_pair_bits(rh, c0 + 2 * j);
+        const float lo = (b & 0xffffu) >= thr ? bf2f((uint16_t)(aw[j] & 0xffff)) * ik : 0.f;
+        const float hi = (b >> 16) >= thr ? bf2f((uint16_t)(aw[j] >> 16)) * ik : 0.f;
         w[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
     }
     *(uint4 *)(out + i) = make_uint4(w[0], w[1], w[2], w[3]);
@@ -614,11 +619,11 @@ extern "C" int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, con
     return LAUNCH_OK();
 }
 
-extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, float drop_p, uint32_t seed, void *stream)
+extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, int cols, float drop_p, uint32_t seed, void *stream)
 {
-    if (!x || !out || n < 8 || (n & 7) || drop_p <= 0.f || drop_p >= 1.f || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return -1;
+    if (!x || !out || n < 8 || (n & 7) || cols < 8 || (cols & 7) || n % cols || drop_p <= 0.f || drop_p >= 1.f || ((uintptr_t)x & 15) || ((uintptr_t)out & 15)) return -1;
     hipLaunchKernelGGL(dropout_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, (uint16_t *)out,
-                       (long long)n, drop_p, seed);
+                       (long long)n, cols, drop_p, seed);
     return LAUNCH_OK();
 }
 

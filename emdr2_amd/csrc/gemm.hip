@@ -32,7 +32,7 @@ struct GemmParams {
     float alpha;
     int gelu, out_f32;
     float drop_p;             // dropout on (acc*alpha + bias [gelu]) before the residual add: bias_dropout_add (transformer.py:397-413)
-    uint32_t seed;            // keep bit = emdr2_keep(seed, m * N + n)
+    uint32_t seed;            // keep bit = emdr2_keep(row_hash(seed, m), n, thr)
     int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
 
@@ -186,9 +186,14 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
                         for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
                     }
                     if (p.drop_p > 0.f) {
-                        const float ik = 1.f / (1.f - p.drop_p);
+                        const float ik = emdr2_keep_scale(p.drop_p);
+                        const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)m), thr = emdr2_drop_thr(p.drop_p);
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = emdr2_keep(p.seed, (unsigned long long)m * p.N + ncol + j, p.drop_p) ? v[j] * ik : 0.f;
+                        for (int j = 0; j < 4; ++j) {
+                            const uint32_t bits = emdr2_pair_bits(rh, (uint32_t)(ncol + 2 * j));
+                            v[2 * j] = (bits & 0xffffu) >= thr ? v[2 * j] * ik : 0.f;
+                            v[2 * j + 1] = (bits >> 16) >= thr ? v[2 * j + 1] * ik : 0.f;
+                        }
                     }
                     if (p.R) {
                         const uint4 rr = *(const uint4 *)((const uint16_t *)p.R + o);
@@ -225,7 +230,7 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
                 float v = acc[mi][ni][r] * p.alpha + bias;
                 if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
                 if (p.gelu) v = gelu_erf(v);
-                if (p.drop_p > 0.f) v = emdr2_keep(p.seed, (unsigned long long)m * p.N + n, p.drop_p) ? v / (1.f - p.drop_p) : 0.f;
+                if (p.drop_p > 0.f) v = emdr2_keep(emdr2_row_hash(p.seed, (unsigned long long)m), (uint32_t)n, emdr2_drop_thr(p.drop_p)) ? v * emdr2_keep_scale(p.drop_p) : 0.f;
                 if (p.R) v += bf16_to_f32(((const uint16_t *)p.R)[o]);
                 if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
                 else if (p.out_f32) ((float *)p.C)[o] = v;

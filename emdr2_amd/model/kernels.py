@@ -81,6 +81,19 @@ def weight_grad_nt(dyT, xT):
     return gemm_nt(dyT, M, xT, M, c, Kd, N, Kd, M, split_k=split)
 
 
+def weight_grad_tn(dy, x, colsum=None):
+    """dW [N, K] fp32 = dy [M, N]^T @ x [M, K] straight from the row-major activations (gemm_tn.hip); `colsum` (fp32 [N]) accumulates the
+    bias gradient.  Few output tiles, reduction over all tokens -> the reduction is split across the chip."""
+    M, N = dy.shape
+    Kd = x.shape[1]
+    tiles = ((N + 255) // 256) * ((Kd + 255) // 256)
+    split = max(1, min(512 // max(tiles, 1), M // 4096))
+    c = (torch.zeros if split > 1 else torch.empty)((N, Kd), dtype=torch.float32, device=dy.device)
+    _native.check(_lib().emdr2_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), c.data_ptr(), Kd, N, Kd, M, split, _ptr(colsum),
+                                            _sp()), "gemm_tn_bf16")
+    return c
+
+
 def transpose(x2d, colsum=None):
     """[R, C] bf16 contiguous -> [C, R]; optional fp32 column sums accumulated into `colsum`."""
     R, C = x2d.shape
@@ -187,7 +200,7 @@ class LinearFn(torch.autograd.Function):
         dres = dy if ctx.has_res else None
         if ctx.drop_p > 0.0:                                                              # the epilogue's dropout mask, regenerated
             dmask = torch.empty_like(dy2)
-            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), ctx.drop_p, ctx.seed, _sp()), "dropout")
+            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), N, ctx.drop_p, ctx.seed, _sp()), "dropout")
             dy2 = dmask
         if ctx.gelu:
             dpre = torch.empty_like(dy2)
@@ -199,11 +212,9 @@ class LinearFn(torch.autograd.Function):
             dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                      # [M,N] x [K,N]^T
         if weight.requires_grad:
             db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias is not None else None
-            dyT = transpose(dy2, colsum=db)                                               # [N, M] (+ bias gradient)
-            xT = transpose(x2)                                                            # [K, M]
             if M % 32:
                 raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
-            dW = weight_grad_nt(dyT, xT)                                                  # [N, K] fp32 (split-K over the tokens)
+            dW = weight_grad_tn(dy2, x2, colsum=db)                                       # [N, K] fp32 = dy^T x (+ bias gradient), no transposes
             if ctx.row_perm is not None:                                                  # back to the checkpoint's interleaved row order
                 un = torch.empty_like(dW); un[ctx.row_perm] = dW; dW = un
                 if bias is not None:

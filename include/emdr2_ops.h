@@ -18,8 +18,8 @@ extern "C" {
  * C[b1,b2][m,n] = epi( alpha * sum_k A[b1,b2][m,k] * B[b1,b2][n,k] ),  epi = (+bias[n]) -> (GELU) -> (dropout) -> (+residual[m,n])
  * Replaces F.linear (mpu/layers.py:255,353), baddbmm/bmm (transformer.py:309-312,371), bias+GELU
  * (transformer.py:103-104; exact erf), bias-dropout-add (transformer.py:397-413).
- * drop_p > 0 (unbatched, no split-K): element (m, n) is kept iff uniform01(seed, m * N + n) >= drop_p and scaled by 1/(1-drop_p);
- * emdr2_dropout() applies the same mask to the incoming gradient in the backward.
+ * drop_p > 0 (unbatched, no split-K): element (m, n) is kept iff keep(seed, row m, column n) of csrc/rng.h (drop_p quantised to 2^-16);
+ * survivors are scaled by 1/(1-p); emdr2_dropout() applies the same mask to the incoming gradient in the backward.
  * K % 32 == 0; lda, ldb and the A/B batch strides multiples of 8 elements; A, B 16-byte aligned.
  * pre_act (optional, bf16, indexed like C): value before GELU, kept for the backward.
  * split_k > 1: the reduction is cut into split_k slices accumulated with fp32 atomics into a PRE-ZEROED fp32 C (weight
@@ -30,8 +30,16 @@ int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, v
                        float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
                        int split_k, float drop_p, uint32_t seed, void *stream);
 
-/* out[i] = keep(seed, i) ? x[i] / (1 - p) : 0 over n contiguous bf16 elements (the mask of a dropout site, regenerated). */
-int emdr2_dropout(const void *x, void *out, int64_t n, float drop_p, uint32_t seed, void *stream);
+/* Weight-gradient GEMM, "TN" form: C[i, j] (fp32) = sum_r A[r, i] * B[r, j], A [R, I] and B [R, J] row-major bf16 (dW = dy^T x without
+ * transposing either operand through HBM: LDS transpose reads, see csrc/gemm_tn.hip).  Replaces the autograd weight gradient of F.linear
+ * (mpu/layers.py:255,353).  R % 32 == 0, I, J, lda, ldb multiples of 8.  colsum_a (optional, fp32 [I]) accumulates the column sums
+ * of A (the bias gradient).  split_k > 1 accumulates reduction slices with atomics into a PRE-ZEROED C. */
+int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, int I, int J, int R, int split_k,
+                       float *colsum_a, void *stream);
+
+/* out[r, c] = keep(seed, r, c) ? x[r, c] / (1 - p) : 0 over a contiguous bf16 [n / cols, cols] tensor (the mask of a dropout site,
+ * regenerated; cols % 8 == 0). */
+int emdr2_dropout(const void *x, void *out, int64_t n, int cols, float drop_p, uint32_t seed, void *stream);
 
 /* out[b1,b2][c, r] = in[b1,b2][r, c] (bf16), optional fp32 column sums colsum[c] += sum_r in[r, c] over all batches
  * (bias gradients: the reduce of the reference's autograd over [s, b]). */
@@ -51,7 +59,7 @@ int emdr2_layernorm_bwd(const void *dy, const void *x, const float *gamma, const
  * (bert/t5_attention_mask_func), masks derived on the fly from token ids (pad id 0; mask_creation_utils.py:17-42),
  * `causal` adds the history mask.  scores bf16 [batch, heads, sq, sk] in place; m, l: row max / sum-exp (fp32 [batch, heads, sq]).
  * drop_p > 0: attention dropout (transformer.py:262,366) applied to the stored probabilities AFTER normalisation (m, l are those of the
- * un-dropped softmax); keep bit = uniform01(seed, row * sk + k) >= drop_p, row = (b * heads + n) * sq + q.
+ * un-dropped softmax); keep bit = keep(seed, row, k) of csrc/rng.h, row = (b * heads + n) * sq + q.
  * _bwd: dprobs -> dscores in place, d = rowsum(P*dP_eff).  With m, l given, `probs` holds the raw scaled scores and P is rebuilt from
  * the statistics (the forward need not keep the [sq, sk] probabilities); dropout requires that form.
  * _t: transposed twin for the attention backward: S^T -> dropped P^T, dP^T -> dS^T (see elementwise.hip). */
@@ -65,8 +73,8 @@ int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, c
 /* Fused attention forward for head_dim 64, sk % 64 == 0 (transformer.py:283-381 without the [sq, sk] score matrix): o = dropout(softmax(mask(q k^T
  * scale))) v.  q [b, sq, heads, 64] / k [b, sk, heads, 64] strided views (element strides: batch, sequence, head; last dim contiguous),
  * vT [b, heads, 64, sk], o [b, sq, heads, 64] contiguous, masks from token ids (pad id 0) + causal, masked scores REPLACED by -10000.
- * m / l (row max and row sum of exp, fp32 [b, heads, sq]) feed the backward.  Dropout keep-bit = uniform01(seed, ((b*heads+n)*sq+q)*sk+key)
- * >= drop_p (same generator as emdr2_dropout / emdr2_softmax_from_stats).  Returns -4 for shapes it does not cover. */
+ * m / l (row max and row sum of exp, fp32 [b, heads, sq]) feed the backward.  Dropout keep-bit = keep(seed, row (b*heads+n)*sq+q,
+ * column key) of csrc/rng.h (same generator as emdr2_dropout / emdr2_softmax_mask_*).  Returns -4 for shapes it does not cover. */
 int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
                         const void *vT, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int head_dim,
                         int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream);
@@ -75,7 +83,7 @@ int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
 int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int64_t n, void *stream);
 
 /* Embedding.forward (language_model.py:169-181): out[t] = dropout(W[ids[t]] + P[t % S] (+ T[types[t]])); bwd scatter-adds the (masked)
- * gradient into fp32 grads.  Dropout index = t * H + i. */
+ * gradient into fp32 grads.  Dropout element = (row t, column i). */
 int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, const void *W, const void *P, const void *T, void *out, int64_t tokens, int S,
                         int H, float drop_p, uint32_t seed, void *stream);
 int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S, int H,

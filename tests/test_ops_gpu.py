@@ -109,7 +109,7 @@ def _dropout_mask(shape, p, seed):
     nat, lib = _lib()
     ones = torch.ones(shape, dtype=torch.bfloat16, device="cuda")
     out = torch.empty_like(ones)
-    nat.check(lib.emdr2_dropout(ones.data_ptr(), out.data_ptr(), ones.numel(), p, seed, nat.stream_ptr()), "dropout")
+    nat.check(lib.emdr2_dropout(ones.data_ptr(), out.data_ptr(), ones.numel(), shape[-1], p, seed, nat.stream_ptr()), "dropout")
     torch.cuda.synchronize()
     return out.float()
 
@@ -223,3 +223,19 @@ def test_embedding_dropout_forward_and_backward():
     rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
     assert rel(out, ref) < 1e-2
     assert rel(Wt.grad, Wf.grad) < 2e-2 and rel(Pt.grad, Pf.grad) < 2e-2
+
+
+@pytest.mark.parametrize("M,N,Kd", [(64, 256, 256), (4096, 768, 768), (65536, 768, 512), (2048, 2304, 768), (1024, 40, 72), (8192, 3072, 768)])
+def test_weight_gradient_gemm_tn_with_bias_gradient(M, N, Kd):
+    """dW = dy^T x through the LDS transpose reads (no HBM transposes), asymmetric random operands (a transposed or permuted fragment
+    cannot pass), plus the fused column sums of dy."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(M + N + Kd)
+    dy = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    x = torch.randn((M, Kd), generator=g, device="cuda").bfloat16()
+    db = torch.zeros(N, device="cuda")
+    dW = K.weight_grad_tn(dy, x, colsum=db)
+    torch.cuda.synchronize()
+    ref = dy.float().T @ x.float()
+    assert torch.allclose(dW, ref, rtol=2e-3, atol=2e-3 * (M ** 0.5))
+    assert torch.allclose(db, dy.float().sum(0), rtol=1e-3, atol=1e-3 * (M ** 0.5))

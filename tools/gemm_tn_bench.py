@@ -1,0 +1,24 @@
+"""Weight-gradient GEMM (TN, LDS transpose reads) timing at the reader's shapes (GPU)."""
+import time
+
+import torch
+
+from emdr2_amd.model import kernels as K
+
+for M, N, Kd in [(3200 * 512, 768, 768), (3200 * 512, 3072, 768), (3200 * 512, 768, 3072), (3200 * 512, 2304, 768), (3200 * 256, 768, 768)]:
+    g = torch.Generator(device="cuda").manual_seed(0)
+    dy = torch.randn((M, N), generator=g, device="cuda").bfloat16()
+    x = torch.randn((M, Kd), generator=g, device="cuda").bfloat16()
+    db = torch.zeros(N, device="cuda")
+    for _ in range(2):
+        K.weight_grad_tn(dy, x, colsum=db)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 5
+    for _ in range(n):
+        K.weight_grad_tn(dy, x, colsum=db)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / n
+    print("dW[%d,%d] over %d tokens: %.3f ms  %.1f TFLOP/s  (%.0f GB/s operand read)" % (N, Kd, M, dt * 1e3, 2.0 * M * N * Kd / dt / 1e12,
+                                                                                     2.0 * M * (N + Kd) / dt / 1e9))
+    del dy, x
