@@ -1,0 +1,435 @@
+// emdr2_amd/csrc/attention_bwd.hip -- fused attention backward for head dim 64 (include/emdr2_ops.h: emdr2_attention_bwd).
+//
+// Gradient of o = dropout(softmax(mask(q k^T scale))) v (reference: the autograd of transformer.py:283-381) without ever writing a
+// [sq, sk] matrix.  The probabilities are rebuilt from the forward's row statistics (m, l) in both orientations:
+//
+//   dq kernel  (a wave owns 32 queries, streams 64-key blocks of K and V through LDS)
+//       S^T = K Q^T, dP^T = V dO^T          MFMA A = K / V rows (ds_read_b128), B = Q / dO fragments held in registers
+//       dS^T = P^T o (dP^T_eff - D)         D[q] = dO[q,:] . O[q,:] (computed here, written for the second kernel)
+//       dQ^T += K^T dS^T                    MFMA A = K^T gathered from the SAME [key][d] tile with ds_read_b64_tr_b16, B = dS^T from the
+//                                           accumulator registers (the key subset a lane owns is used as the k index on both sides)
+//   dk/dv kernel (a wave owns 32 keys, streams 64-query blocks of Q and dO plus their row statistics through LDS)
+//       S = Q K^T, dP = dO V^T              MFMA A = Q / dO rows, B = K / V fragments held in registers
+//       dV^T += dO^T P_dropped, dK^T += Q^T dS     A = dO^T / Q^T by transpose reads of the same tiles
+//
+// Tiles are [64 rows][64 d] bf16 (128-B rows of eight 16-B granules), granule index XOR f(row) with
+// f(row) = (((row >> 1) & 1) << 2) | ((row >> 2) & 3): conflict-free for the row reads (16 consecutive rows, one granule) and for the
+// transpose reads (4 rows x 4 granules per 32-lane service group).  Masks from token ids (pad id 0) + optional history mask; masked
+// positions get dS = 0 (masked_fill cuts the dependence on the score) while their (normally zero) probability still feeds dV, like
+// the reference.  Dropout bits are regenerated from (seed, row, key) -- csrc/rng.h -- never stored.
+#include "../../include/emdr2_ops.h"
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "rng.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+namespace {
+
+struct BwdParams {
+    const char *q, *k, *v, *o, *dout;
+    char *dq, *dk, *dv;
+    const long long *ids_q, *ids_k;
+    const float *m, *l;
+    float *dstat;                  // D[q] = rowsum(dO o O), [b, heads, sq]
+    long long q_sb, q_ss, q_sn;    // element strides of q (batch, sequence, head); k and v share k_*
+    long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
+    int heads, sq, sk, causal;
+    float scale, drop_p;
+    uint32_t seed;
+};
+
+#define L2E 1.4426950408889634f
+#define MASKED2 (-10000.f * 1.4426950408889634f)
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+__device__ __forceinline__ int tile_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)
+{
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Fragment of the row-major global matrix row: 8 bf16 at d = 16 t + 8 hi for t = 0..3 (the B operand of the "swapped" MFMAs)
+__device__ __forceinline__ void load_row_frags(const char *row, int hi, bf16x8 (&f)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f[t] = *(const bf16x8 *)(row + (16 * t + 8 * hi) * 2);
+}
+
+// Row fragment (MFMA A operand, 8 consecutive d of one tile row) from a swizzled tile
+__device__ __forceinline__ bf16x8 tile_row_frag(const char *tile, int row, int gran)
+{
+    return *(const bf16x8 *)(tile + row * 128 + ((gran ^ tile_swz(row)) << 4));
+}
+
+// Transposed fragments: for the 16-row k-step starting at tile row `rb` (multiple of 16) the lane (col c = jsub*32 + lane&31, half hi) gets rows
+// rb + 4 hi + {0,1,2,3} and rb + 8 + 4 hi + {0,1,2,3} of column c -- the row subset a lane's accumulator registers 8(u&1)..8(u&1)+7 cover.
+// tr_base[jsub][which] holds the lane's byte address for rb = 0.
+__device__ __forceinline__ void tr_addresses(uint32_t tile_lds, int lane, uint32_t (&base)[2][2])
+{
+    const int t = lane & 15, colgrp = (lane >> 4) & 1, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + colgrp * 16 + (t & 3) * 4;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int row = 4 * hi + 8 * w + (t >> 2);
+            base[j][w] = tile_lds + row * 128 + ((((col >> 3) ^ tile_swz(row))) << 4) + (col & 7) * 2;
+        }
+    }
+}
+// k-step u = 0..3 covers tile rows 16 u .. 16 u + 15: tile_swz(row + 16 u) == tile_swz(row) ^ ... only bits (row>>1)&1 and (row>>2)&3 enter, and
+// 16 u changes neither, so the address moves by the plain 2048-byte offset.
+#define TR_FRAG(dst, base, u)                                                              \
+    do {                                                                                   \
+        uint2 lo_, hi_;                                                                    \
+        TR_READ(lo_, (base)[0], (u) * 2048);                                               \
+        TR_READ(hi_, (base)[1], (u) * 2048);                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo_), "+v"(hi_)::"memory");             \
+        dst = __builtin_bit_cast(bf16x8, make_uint4(lo_.x, lo_.y, hi_.x, hi_.y));          \
+    } while (0)
+
+// ============================================================ dq =====================================================================
+__global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
+{
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];       // 2 stages x (K tile 8 KiB + V tile 8 KiB)
+    __shared__ unsigned long long kmask_s[1024];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, n = blockIdx.y;
+    const int q0 = blockIdx.x * 256 + wave * 32;
+    const int qi = q0 + l31;
+    const bool qvalid = qi < p.sq;
+    const int qc = qvalid ? qi : p.sq - 1;
+    const bool wave_live = q0 < p.sq;
+
+    bf16x8 qf[4], dof[4];
+    load_row_frags(p.q + ((long long)b * p.q_sb + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2, hi, qf);
+    const long long orow = (((long long)b * p.sq + qc) * p.heads + n) * 64;
+    load_row_frags(p.dout + orow * 2, hi, dof);
+    const long long si = ((long long)b * p.heads + n) * p.sq + qc;
+    float Dq;
+    {   // D = dO . O over this row (two half-rows, one per half-wave)
+        bf16x8 of[4];
+        load_row_frags(p.o + orow * 2, hi, of);
+        float acc = 0.f;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const uint4 a = __builtin_bit_cast(uint4, dof[t]), c = __builtin_bit_cast(uint4, of[t]);
+            acc += bf_lo(a.x) * bf_lo(c.x) + bf_hi(a.x) * bf_hi(c.x) + bf_lo(a.y) * bf_lo(c.y) + bf_hi(a.y) * bf_hi(c.y) +
+                   bf_lo(a.z) * bf_lo(c.z) + bf_hi(a.z) * bf_hi(c.z) + bf_lo(a.w) * bf_lo(c.w) + bf_hi(a.w) * bf_hi(c.w);
+        }
+        Dq = acc + __shfl_xor(acc, 32);
+        if (qvalid && hi == 0) p.dstat[si] = Dq;
+    }
+    const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
+    const float sc = p.scale * L2E;
+    const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
+
+    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
+    const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;
+    const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
+    const int nblk = p.sk / 64;
+    auto issue = [&](int blk, int stage) {
+        char *sb = smem + stage * 16384;
+        const long long key = blk * 64 + prow;
+        __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+    };
+    for (int blk = wave; blk < nblk; blk += 8) {
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * 64 + lane] != 0);
+        if (lane == 0) kmask_s[blk] = w;
+    }
+    uint32_t ktr[2][2];
+    tr_addresses((uint32_t)(uintptr_t)smem, lane, ktr);
+
+    floatx16 dqacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dqacc[j][r] = 0.f;
+    const bool drop = p.drop_p > 0.f;
+    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const uint32_t thr = emdr2_drop_thr(p.drop_p);
+    const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)si);
+
+    issue(0, 0);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int stage = blk & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);
+        const unsigned long long kmask = kmask_s[blk];
+        const int key0 = blk * 64;
+        // every (query of this wave, key of this block) pair masked -> dS == 0: nothing to add
+        if (!wave_live || kmask == 0ull || (p.causal && key0 > q0 + 31)) continue;
+        const char *sb = smem + stage * 16384;
+
+        floatx16 sacc[2], pacc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[j][r] = 0.f; pacc[j][r] = 0.f; }
+            const int krow = j * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc[j], 0, 0, 0);
+                pacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, 2 * t + hi), dof[t], pacc[j], 0, 0, 0);
+            }
+        }
+        // dS^T = P^T (dP^T_eff - D); masked -> 0
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint32_t b0 = 0, b1 = 0;
+                if (drop) {
+                    const uint32_t col = (uint32_t)(key0 + j * 32 + 8 * g + 4 * hi);
+                    b0 = emdr2_pair_bits(rh, col); b1 = emdr2_pair_bits(rh, col + 2);
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e;
+                    const int kl = j * 32 + 8 * g + 4 * hi + e;
+                    const bool masked = qpad || !((kmask >> kl) & 1ull) || (p.causal && key0 + kl > qi);
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc, -pm));
+                    float gr = pacc[j][r];
+                    if (drop) {
+                        const uint32_t bits = e < 2 ? b0 : b1;
+                        gr = ((e & 1) ? (bits >> 16) : (bits & 0xffffu)) >= thr ? gr * ik : 0.f;
+                    }
+                    sacc[j][r] = masked ? 0.f : pr * (gr - Dq);
+                }
+            }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r0 = (u & 1) * 8;
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]),
+                                                                      pack_bf16(sacc[u >> 1][r0 + 2], sacc[u >> 1][r0 + 3]),
+                                                                      pack_bf16(sacc[u >> 1][r0 + 4], sacc[u >> 1][r0 + 5]),
+                                                                      pack_bf16(sacc[u >> 1][r0 + 6], sacc[u >> 1][r0 + 7])));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                bf16x8 kt;
+                const uint32_t a0[2] = {ktr[j][0] + (uint32_t)(stage * 16384), ktr[j][1] + (uint32_t)(stage * 16384)};
+                switch (u) {
+                case 0: TR_FRAG(kt, a0, 0); break;
+                case 1: TR_FRAG(kt, a0, 1); break;
+                case 2: TR_FRAG(kt, a0, 2); break;
+                default: TR_FRAG(kt, a0, 3); break;
+                }
+                dqacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dqacc[j], 0, 0, 0);
+            }
+        }
+    }
+    if (qvalid) {
+        uint16_t *drow = (uint16_t *)p.dq + orow;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = j * 32 + 8 * g + 4 * hi;
+                *(uint2 *)(drow + d) = make_uint2(pack_bf16(dqacc[j][4 * g] * p.scale, dqacc[j][4 * g + 1] * p.scale),
+                                                  pack_bf16(dqacc[j][4 * g + 2] * p.scale, dqacc[j][4 * g + 3] * p.scale));
+            }
+    }
+}
+
+// ========================================================== dk, dv ===================================================================
+__global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
+{
+    // 2 stages x (Q tile 8 KiB + dO tile 8 KiB); per-query statistics of the block: pm, D, row hash, flags (64 each)
+    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
+    __shared__ __attribute__((aligned(16))) float st_pm[2][64], st_d[2][64];
+    __shared__ __attribute__((aligned(16))) uint32_t st_rh[2][64];
+    __shared__ unsigned long long st_qreal[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, hi = lane >> 5;
+    const int b = blockIdx.z, n = blockIdx.y;
+    const int k0 = blockIdx.x * 256 + wave * 32;
+    const int key = k0 + l31;
+    const bool wave_live = k0 < p.sk;                                   // sk % 64 == 0: a wave's 32 keys are all valid or all out of range
+    const int kc = wave_live ? key : p.sk - 1;
+
+    bf16x8 kf[4], vf[4];
+    load_row_frags(p.k + ((long long)b * p.k_sb + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
+    load_row_frags(p.v + ((long long)b * p.v_sb + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
+    const bool kpad = !wave_live || p.ids_k[(long long)b * p.sk + kc] == 0;
+    const float sc = p.scale * L2E;
+
+    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
+    const char *q_src = p.q + ((long long)b * p.q_sb + (long long)n * p.q_sn) * 2 + pslot * 16;
+    const char *o_src = p.dout + (((long long)b * p.sq) * p.heads + n) * 128 + pslot * 16;
+    const int nblk = (p.sq + 63) / 64;
+    const long long sbase = ((long long)b * p.heads + n) * p.sq;
+    auto issue = [&](int blk, int stage) {
+        char *sb = smem + stage * 16384;
+        long long qr = blk * 64 + prow; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
+        __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+    };
+    // per-query statistics of a block, loaded by wave 0 one block ahead into registers and written to LDS a block later, so the
+    // global-load latency never sits between a barrier and the tiles' DMA
+    float nx_pm = 0.f, nx_d = 0.f;
+    uint32_t nx_rh = 0;
+    unsigned long long nx_real = 0;
+    auto load_stats = [&](int blk) {
+        const int qq = blk * 64 + lane;
+        const bool valid = qq < p.sq;
+        const long long si = sbase + (valid ? qq : p.sq - 1);
+        nx_pm = p.m[si] * L2E + __log2f(p.l[si]);
+        nx_d = p.dstat[si];
+        nx_rh = emdr2_row_hash(p.seed, (unsigned long long)si);
+        nx_real = __builtin_amdgcn_ballot_w64(valid && p.ids_q[(long long)b * p.sq + (valid ? qq : 0)] != 0);
+    };
+    auto store_stats = [&](int stage) {
+        st_pm[stage][lane] = nx_pm; st_d[stage][lane] = nx_d; st_rh[stage][lane] = nx_rh;
+        if (lane == 0) st_qreal[stage] = nx_real;
+    };
+    uint32_t qtr[2][2], otr[2][2];
+    tr_addresses((uint32_t)(uintptr_t)smem, lane, qtr);
+    tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, otr);
+
+    floatx16 dkacc[2], dvacc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dkacc[j][r] = 0.f; dvacc[j][r] = 0.f; }
+    const bool drop = p.drop_p > 0.f;
+    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const uint32_t thr = emdr2_drop_thr(p.drop_p);
+    const uint32_t colmul = ((uint32_t)kc >> 1) * 0x9e3779b1u;           // this lane's column-pair term of emdr2_pair_bits
+    const bool codd = kc & 1;
+
+    if (wave == 0) { load_stats(0); store_stats(0); if (nblk > 1) load_stats(1); }
+    issue(0, 0);
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int stage = blk & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (blk + 1 < nblk) {
+            if (wave == 0) store_stats(stage ^ 1);
+            issue(blk + 1, stage ^ 1);
+            if (wave == 0 && blk + 2 < nblk) load_stats(blk + 2);
+        }
+        const int qb0 = blk * 64;
+        // keys of this wave all ahead of every query of the block: P == 0 exactly and dS == 0
+        if (!wave_live || (p.causal && k0 > qb0 + 63)) continue;
+        const unsigned long long qreal = st_qreal[stage];
+        const char *sb = smem + stage * 16384;
+
+        // the block's 64 queries in two halves of 32 (keeps the live accumulators at dK, dV + one S / dP pair)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            floatx16 sacc, pacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            const int qrow = j * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, qrow, 2 * t + hi), kf[t], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, qrow, 2 * t + hi), vf[t], pacc, 0, 0, 0);
+            }
+            // this lane: one key, queries ql = j*32 + 8g + 4hi + e.  sacc <- dS, pacc <- dropped P
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int ql0 = j * 32 + 8 * g + 4 * hi;
+                const float4 pm4 = *(const float4 *)&st_pm[stage][ql0], d4 = *(const float4 *)&st_d[stage][ql0];
+                uint4 rh4 = make_uint4(0, 0, 0, 0);
+                if (drop) rh4 = *(const uint4 *)&st_rh[stage][ql0];
+                const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+                const uint32_t rhv[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, ql = ql0 + e, qg = qb0 + ql;
+                    const bool qv = qg < p.sq;
+                    const bool masked = kpad || !((qreal >> ql) & 1ull) || (p.causal && key > qg);
+                    float pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
+                    if (!qv) pr = 0.f;                                    // rows beyond sq do not exist
+                    float gr = pacc[r], pd = pr;
+                    if (drop) {
+                        const uint32_t bits = emdr2_mix32(colmul ^ rhv[e]);
+                        const bool keep = (codd ? (bits >> 16) : (bits & 0xffffu)) >= thr;
+                        gr = keep ? gr * ik : 0.f;
+                        pd = keep ? pr * ik : 0.f;
+                    }
+                    sacc[r] = masked ? 0.f : pr * (gr - dv_[e]);
+                    pacc[r] = pd;
+                }
+            }
+            // dV^T += dO^T P_d ; dK^T += Q^T dS  (k index = the 16 queries of k-step u = 2j, 2j+1)
+#pragma unroll
+            for (int uu = 0; uu < 2; ++uu) {
+                const int r0 = uu * 8;
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(pacc[r0], pacc[r0 + 1]), pack_bf16(pacc[r0 + 2], pacc[r0 + 3]),
+                                                                         pack_bf16(pacc[r0 + 4], pacc[r0 + 5]), pack_bf16(pacc[r0 + 6], pacc[r0 + 7])));
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[r0], sacc[r0 + 1]), pack_bf16(sacc[r0 + 2], sacc[r0 + 3]),
+                                                                          pack_bf16(sacc[r0 + 4], sacc[r0 + 5]), pack_bf16(sacc[r0 + 6], sacc[r0 + 7])));
+#pragma unroll
+                for (int jd = 0; jd < 2; ++jd) {
+                    bf16x8 ot, qt;
+                    const uint32_t ao[2] = {otr[jd][0] + (uint32_t)(stage * 16384), otr[jd][1] + (uint32_t)(stage * 16384)};
+                    const uint32_t aq[2] = {qtr[jd][0] + (uint32_t)(stage * 16384), qtr[jd][1] + (uint32_t)(stage * 16384)};
+                    switch (2 * j + uu) {
+                    case 0: TR_FRAG(ot, ao, 0); TR_FRAG(qt, aq, 0); break;
+                    case 1: TR_FRAG(ot, ao, 1); TR_FRAG(qt, aq, 1); break;
+                    case 2: TR_FRAG(ot, ao, 2); TR_FRAG(qt, aq, 2); break;
+                    default: TR_FRAG(ot, ao, 3); TR_FRAG(qt, aq, 3); break;
+                    }
+                    dvacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pf, dvacc[jd], 0, 0, 0);
+                    dkacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dkacc[jd], 0, 0, 0);
+                }
+            }
+        }
+    }
+    if (wave_live) {
+        uint16_t *krow = (uint16_t *)p.dk + (((long long)b * p.sk + key) * p.heads + n) * 64;
+        uint16_t *vrow = (uint16_t *)p.dv + (((long long)b * p.sk + key) * p.heads + n) * 64;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int d = j * 32 + 8 * g + 4 * hi;
+                *(uint2 *)(krow + d) = make_uint2(pack_bf16(dkacc[j][4 * g] * p.scale, dkacc[j][4 * g + 1] * p.scale),
+                                                  pack_bf16(dkacc[j][4 * g + 2] * p.scale, dkacc[j][4 * g + 3] * p.scale));
+                *(uint2 *)(vrow + d) = make_uint2(pack_bf16(dvacc[j][4 * g], dvacc[j][4 * g + 1]), pack_bf16(dvacc[j][4 * g + 2], dvacc[j][4 * g + 3]));
+            }
+    }
+}
+
+} // namespace
+
+extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, void *dk,
+                                   void *dv, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
+                                   int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
+{
+    if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
+    if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536) return -4;
+    const int64_t strides[9] = {q_sb, q_ss, q_sn, k_sb, k_ss, k_sn, v_sb, v_ss, v_sn};
+    for (int i = 0; i < 9; ++i)
+        if (strides[i] & 7) return -4;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) ||
+        ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7) || drop_p < 0.f || drop_p >= 1.f)
+        return -1;
+    BwdParams p;
+    p.q = (const char *)q; p.k = (const char *)k; p.v = (const char *)v; p.o = (const char *)o; p.dout = (const char *)dout;
+    p.dq = (char *)dq; p.dk = (char *)dk; p.dv = (char *)dv;
+    p.ids_q = (const long long *)ids_q; p.ids_k = (const long long *)ids_k; p.m = m; p.l = l; p.dstat = dstat;
+    p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
+    p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((sq + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((sk + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

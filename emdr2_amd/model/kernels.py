@@ -294,13 +294,13 @@ class AttentionCoreFn(torch.autograd.Function):
             _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal),
                                                         m.data_ptr(), l.data_ptr(), float(drop_p), int(seed), _sp()), "softmax_fwd")
             gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
-        ctx.save_for_backward(q, k, v, m, l, ids_q, ids_k)
+        ctx.save_for_backward(q, k, v, m, l, ids_q, ids_k, ctxo)
         ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
         return ctxo
 
     @staticmethod
     def backward(ctx, dctx):
-        q, k, v, m, l, ids_q, ids_k = ctx.saved_tensors
+        q, k, v, m, l, ids_q, ids_k, ctxo = ctx.saved_tensors
         b, sq, heads, hn = q.shape
         sk = k.shape[1]
         dev = q.device
@@ -309,6 +309,17 @@ class AttentionCoreFn(torch.autograd.Function):
         dctx = dctx.contiguous()
         H = heads * hn
         lib = _lib()
+        if hn == 64 and sk % 64 == 0 and sk <= 65536:                                     # fused: no [sq, sk] matrix, no operand transposes
+            dq = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
+            dk = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
+            dv = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
+            D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
+            _native.check(lib.emdr2_attention_bwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
+                                                  k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), dctx.data_ptr(),
+                                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(),
+                                                  l.data_ptr(), D.data_ptr(), b, heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, _sp()),
+                          "attention_bwd")
+            return dq, dk, dv, None, None, None, None, None
         # main orientation: S = scale Q K^T (recomputed), dP = dctx V^T, dS = P (dP_eff - D) with P rebuilt from (m, l)
         S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),

@@ -29,4 +29,17 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
 fl = 4.0 * b * heads * s * s * hn
+qkv.requires_grad_(True)
+q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+out = K.attention_core(q, k, v, ids, ids, False, drop_p=drop, seed=1)
+w = torch.randn_like(out)
+for _ in range(2):
+    g = torch.autograd.grad(out, qkv, w, retain_graph=True)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(n):
+    g = torch.autograd.grad(out, qkv, w, retain_graph=True)
+torch.cuda.synchronize()
+dtb = (time.perf_counter() - t0) / n
+print("attention bwd: %.3f ms  %.1f TFLOP/s (2.5x forward flops; incl. scatter of dq/dk/dv into the qkv gradient)" % (dtb * 1e3, 2.5 * fl / dtb / 1e12))
 print("attention fwd b=%d s=%d drop=%.2f pad=%.2f: %.3f ms  %.1f TFLOP/s (incl. V transpose)" % (b, s, drop, pad, dt * 1e3, fl / dt / 1e12))
