@@ -39,6 +39,7 @@ struct BwdParams {
     float *dstat;                  // D[q] = rowsum(dO o O), [b, heads, sq]
     long long q_sb, q_ss, q_sn;    // element strides of q (batch, sequence, head); k and v share k_*
     long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
+    long long dq_sb, dq_ss, dkv_sb, dkv_ss;   // element strides (batch, sequence) of the gradient outputs; heads are 64 apart
     int heads, sq, sk, causal;
     float scale, drop_p;
     uint32_t seed;
@@ -233,7 +234,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
         }
     }
     if (qvalid) {
-        uint16_t *drow = (uint16_t *)p.dq + orow;
+        uint16_t *drow = (uint16_t *)p.dq + (long long)b * p.dq_sb + (long long)qi * p.dq_ss + n * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -394,8 +395,8 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
         }
     }
     if (wave_live) {
-        uint16_t *krow = (uint16_t *)p.dk + (((long long)b * p.sk + key) * p.heads + n) * 64;
-        uint16_t *vrow = (uint16_t *)p.dv + (((long long)b * p.sk + key) * p.heads + n) * 64;
+        uint16_t *krow = (uint16_t *)p.dk + (long long)b * p.dkv_sb + (long long)key * p.dkv_ss + n * 64;
+        uint16_t *vrow = (uint16_t *)p.dv + (long long)b * p.dkv_sb + (long long)key * p.dkv_ss + n * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -411,14 +412,14 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
 } // namespace
 
 extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, void *dk,
-                                   void *dv, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
+                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                                   int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
                                    int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
 {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
     if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536) return -4;
-    const int64_t strides[9] = {q_sb, q_ss, q_sn, k_sb, k_ss, k_sn, v_sb, v_ss, v_sn};
-    for (int i = 0; i < 9; ++i)
+    const int64_t strides[13] = {q_sb, q_ss, q_sn, k_sb, k_ss, k_sn, v_sb, v_ss, v_sn, dq_sb, dq_ss, dkv_sb, dkv_ss};
+    for (int i = 0; i < 13; ++i)
         if (strides[i] & 7) return -4;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 15) || ((uintptr_t)dout & 15) || ((uintptr_t)dq & 7) ||
         ((uintptr_t)dk & 7) || ((uintptr_t)dv & 7) || drop_p < 0.f || drop_p >= 1.f)
@@ -428,6 +429,7 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.dq = (char *)dq; p.dk = (char *)dk; p.dv = (char *)dv;
     p.ids_q = (const long long *)ids_q; p.ids_k = (const long long *)ids_k; p.m = m; p.l = l; p.dstat = dstat;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
+    p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dkv_sb = dkv_sb; p.dkv_ss = dkv_ss;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((sq + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((sk + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);

@@ -266,14 +266,21 @@ def layer_norm(x, gamma, beta, eps=1e-5):
 
 
 class AttentionCoreFn(torch.autograd.Function):
-    """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).  q [b, sq, np, hn], k, v [b, sk, np, hn] are
-    strided views (last dim contiguous) into the projection outputs; masks come from token ids (pad id 0) + optional history mask.
-    Forward: the fused kernel (attention.hip) when hn == 64 and sk % 64 == 0, else QK^T GEMM + softmax kernel + PV GEMM.  Only the row
-    statistics (max, sum-exp) are kept; the backward rebuilds the probabilities from them in both orientations."""
+    """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).
+    Inputs are the projection outputs themselves: self-attention passes `qsrc` = the packed [b, s, 3, np, hn] QKV tensor (kvsrc None),
+    cross-attention `qsrc` = [b, sq, np, hn] and `kvsrc` = the packed [b, sk, 2, np, hn] KV tensor.  The kernels read q, k, v as strided
+    slices and the backward writes dq, dk, dv straight into ONE packed gradient (no select_backward zero-fill + add chains).
+    Masks come from token ids (pad id 0) + optional history mask.  hn == 64 and sk % 64 == 0 run the fused kernels (attention.hip,
+    attention_bwd.hip); other shapes run QK^T GEMM + softmax kernel + PV GEMM.  Only the row statistics (max, sum-exp) and the output are
+    kept; the backward rebuilds the probabilities from them."""
 
     @staticmethod
-    def forward(ctx, q, k, v, ids_q, ids_k, causal, drop_p=0.0, seed=0):
-        _check_bf16(q, k, v)
+    def forward(ctx, qsrc, kvsrc, ids_q, ids_k, causal, drop_p=0.0, seed=0):
+        _check_bf16(qsrc, kvsrc)
+        if kvsrc is None:
+            q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
+        else:
+            q, k, v = qsrc, kvsrc[:, :, 0], kvsrc[:, :, 1]
         b, sq, heads, hn = q.shape
         sk = k.shape[1]
         dev = q.device
@@ -294,13 +301,21 @@ class AttentionCoreFn(torch.autograd.Function):
             _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal),
                                                         m.data_ptr(), l.data_ptr(), float(drop_p), int(seed), _sp()), "softmax_fwd")
             gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
-        ctx.save_for_backward(q, k, v, m, l, ids_q, ids_k, ctxo)
+        ctx.save_for_backward(qsrc, kvsrc, m, l, ids_q, ids_k, ctxo)
         ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
         return ctxo
 
     @staticmethod
     def backward(ctx, dctx):
-        q, k, v, m, l, ids_q, ids_k, ctxo = ctx.saved_tensors
+        qsrc, kvsrc, m, l, ids_q, ids_k, ctxo = ctx.saved_tensors
+        if kvsrc is None:
+            q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
+            dqsrc, dkvsrc = torch.empty_like(qsrc), None
+            dq, dk, dv = dqsrc[:, :, 0], dqsrc[:, :, 1], dqsrc[:, :, 2]
+        else:
+            q, k, v = qsrc, kvsrc[:, :, 0], kvsrc[:, :, 1]
+            dqsrc, dkvsrc = torch.empty_like(qsrc), torch.empty_like(kvsrc)
+            dq, dk, dv = dqsrc, dkvsrc[:, :, 0], dkvsrc[:, :, 1]
         b, sq, heads, hn = q.shape
         sk = k.shape[1]
         dev = q.device
@@ -309,30 +324,26 @@ class AttentionCoreFn(torch.autograd.Function):
         dctx = dctx.contiguous()
         H = heads * hn
         lib = _lib()
+        D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         if hn == 64 and sk % 64 == 0 and sk <= 65536:                                     # fused: no [sq, sk] matrix, no operand transposes
-            dq = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
-            dk = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
-            dv = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
-            D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
             _native.check(lib.emdr2_attention_bwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
                                                   k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), dctx.data_ptr(),
-                                                  dq.data_ptr(), dk.data_ptr(), dv.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(),
-                                                  l.data_ptr(), D.data_ptr(), b, heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, _sp()),
-                          "attention_bwd")
-            return dq, dk, dv, None, None, None, None, None
+                                                  dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dv.data_ptr(), dk.stride(0),
+                                                  dk.stride(1), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(), D.data_ptr(), b,
+                                                  heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, _sp()), "attention_bwd")
+            return dqsrc, dkvsrc, None, None, None, None, None
         # main orientation: S = scale Q K^T (recomputed), dP = dctx V^T, dS = P (dP_eff - D) with P rebuilt from (m, l)
         S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
                 sq * sk, alpha=scale)
         dP = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(dctx, H, v, v.stride(1), dP, sk, sq, sk, hn, b, sq * H, v.stride(0), heads * sq * sk, heads, hn, v.stride(2), sq * sk)
-        D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         _native.check(lib.emdr2_softmax_mask_bwd(S.data_ptr(), dP.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(), b,
                                                  heads, sq, sk, causal, ctx.drop_p, ctx.seed, D.data_ptr(), _sp()), "softmax_bwd")
         del S
-        dq = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
         kT = head_transpose(k, b, sk, heads, hn)
-        gemm_nt(dP, sk, kT, sk, dq, H, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * H, heads, sq * sk, hn * sk, hn, alpha=scale)
+        gemm_nt(dP, sk, kT, sk, dq, dq.stride(1), sq, hn, sk, b, heads * sq * sk, heads * hn * sk, dq.stride(0), heads, sq * sk, hn * sk, hn,
+                alpha=scale)
         del dP
         # transposed orientation: S^T, dP^T recomputed in the layout dK / dV need (no [sq, sk] transposes)
         St = torch.empty((b, heads, sk, sq), dtype=BF16, device=dev)
@@ -343,16 +354,16 @@ class AttentionCoreFn(torch.autograd.Function):
         _native.check(lib.emdr2_softmax_mask_t(St.data_ptr(), dPt.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(),
                                                D.data_ptr(), b, heads, sq, sk, causal, ctx.drop_p, ctx.seed, _sp()), "softmax_t")
         qT = head_transpose(q, b, sq, heads, hn)
-        dk = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
-        gemm_nt(dPt, sq, qT, sq, dk, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn, alpha=scale)
+        gemm_nt(dPt, sq, qT, sq, dk, dk.stride(1), sk, hn, sq, b, heads * sk * sq, heads * hn * sq, dk.stride(0), heads, sk * sq, hn * sq, hn,
+                alpha=scale)
         dctxT = head_transpose(dctx.view(b, sq, heads, hn), b, sq, heads, hn)
-        dv = torch.empty((b, sk, heads, hn), dtype=BF16, device=dev)
-        gemm_nt(St, sq, dctxT, sq, dv, H, sk, hn, sq, b, heads * sk * sq, heads * hn * sq, sk * H, heads, sk * sq, hn * sq, hn)
-        return dq, dk, dv, None, None, None, None, None
+        gemm_nt(St, sq, dctxT, sq, dv, dv.stride(1), sk, hn, sq, b, heads * sk * sq, heads * hn * sq, dv.stride(0), heads, sk * sq, hn * sq, hn)
+        return dqsrc, dkvsrc, None, None, None, None, None
 
 
-def attention_core(q, k, v, ids_q, ids_k, causal=False, drop_p=0.0, seed=0):
-    return AttentionCoreFn.apply(q, k, v, ids_q, ids_k, causal, drop_p, seed)
+def attention_core(qsrc, kvsrc, ids_q, ids_k, causal=False, drop_p=0.0, seed=0):
+    """qsrc packed [b, s, 3, np, hn] with kvsrc None (self-attention), or qsrc [b, sq, np, hn] + kvsrc packed [b, sk, 2, np, hn]."""
+    return AttentionCoreFn.apply(qsrc, kvsrc, ids_q, ids_k, causal, drop_p, seed)
 
 
 class EmbeddingFn(torch.autograd.Function):

@@ -95,17 +95,17 @@ class ParallelAttention(torch.nn.Module):
 
     def forward(self, x, ids_q, ids_k, causal, residual, encoder_output=None):
         b, sq, h = x.shape
+        pa = self.attention_dropout if self.training else 0.0
+        ph = self.hidden_dropout if self.training else 0.0
+        seed = K.DROPOUT.seed(self._site_attn) if pa else 0
         if self.attention_type == "self":
             mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(b, sq, 3, self.heads, self.hn)
-            q, k, v = mixed[:, :, 0], mixed[:, :, 1], mixed[:, :, 2]
+            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
         else:
             sk = encoder_output.shape[1]
             kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
-            k, v = kv[:, :, 0], kv[:, :, 1]
             q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
-        pa = self.attention_dropout if self.training else 0.0
-        ph = self.hidden_dropout if self.training else 0.0
-        ctx = K.attention_core(q, k, v, ids_q, ids_k, causal, drop_p=pa, seed=K.DROPOUT.seed(self._site_attn) if pa else 0).view(b, sq, h)
+            ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
 

@@ -79,11 +79,13 @@ int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
                         const void *vT, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int head_dim,
                         int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream);
 
-/* Fused attention backward for the same shapes (csrc/attention_bwd.hip): dq, dk, dv [b, s, heads, 64] contiguous from q, k, v (strided views),
+/* Fused attention backward for the same shapes (csrc/attention_bwd.hip): dq, dk, dv [b, s, heads, 64] with caller-given batch / sequence element
+ * strides (heads 64 apart: they may be slices of one packed QKV gradient) from q, k, v (strided views),
  * the forward output o and its gradient dout (contiguous), and the forward's m, l.  dstat (fp32 [b, heads, sq]) is scratch for
  * D = rowsum(dout * o).  Same masks, scale and dropout stream as the forward. */
 int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                        const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, void *dk, void *dv,
+                        const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb, int64_t dq_ss,
+                        void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss,
                         const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch, int heads, int sq,
                         int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream);
 

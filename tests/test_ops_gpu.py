@@ -132,26 +132,39 @@ def _attention_case(b, heads, sq, sk, causal, drop_p, seed, gen_seed):
     from emdr2_amd.model import kernels as K
     g = torch.Generator(device="cuda").manual_seed(gen_seed)
     hn = 64
-    q = torch.randn((b, sq, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
-    kv = torch.randn((b, sk, 2, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    packed = sq == sk                                                   # self-attention: one packed [b, s, 3, np, hn] QKV tensor
+    if packed:
+        qkv = torch.randn((b, sq, 3, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    else:
+        q = torch.randn((b, sq, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
+        kv = torch.randn((b, sk, 2, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
     ids_q = torch.randint(1, 100, (b, sq), generator=g, device="cuda")
     ids_k = ids_q if sq == sk else torch.randint(1, 100, (b, sk), generator=g, device="cuda")
     for i in range(b):                                                  # ragged padding; row b-1 of ids_q fully padded exercises uniform rows
         ids_k[i, sk - 7 * i - 3:] = 0
         if sq != sk:
             ids_q[i, sq - i - 1:] = 0
-    out = K.attention_core(q, kv[:, :, 0], kv[:, :, 1], ids_q, ids_k, causal, drop_p=drop_p, seed=seed)
+    out = K.attention_core(qkv, None, ids_q, ids_k, causal, drop_p=drop_p, seed=seed) if packed else \
+        K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=drop_p, seed=seed)
     w = torch.randn(out.shape, generator=g, device="cuda")
     (out.float() * w).sum().backward()
     mask = _dropout_mask((b, heads, sq, sk), drop_p, seed) if drop_p > 0 else None
-    qf = q.detach().float().requires_grad_(True)
-    kvf = kv.detach().float().requires_grad_(True)
-    ref = _attention_reference(qf, kvf[:, :, 0], kvf[:, :, 1], ids_q, ids_k, causal, mask)
+    if packed:
+        qkvf = qkv.detach().float().requires_grad_(True)
+        ref = _attention_reference(qkvf[:, :, 0], qkvf[:, :, 1], qkvf[:, :, 2], ids_q, ids_k, causal, mask)
+    else:
+        qf = q.detach().float().requires_grad_(True)
+        kvf = kv.detach().float().requires_grad_(True)
+        ref = _attention_reference(qf, kvf[:, :, 0], kvf[:, :, 1], ids_q, ids_k, causal, mask)
     (ref * w).sum().backward()
     rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
     assert rel(out, ref) < 2e-2, ("out", rel(out, ref))
-    assert rel(q.grad, qf.grad) < 3e-2, ("dq", rel(q.grad, qf.grad))
-    assert rel(kv.grad, kvf.grad) < 3e-2, ("dkv", rel(kv.grad, kvf.grad))
+    if packed:
+        for i, name in enumerate(("dq", "dk", "dv")):
+            assert rel(qkv.grad[:, :, i], qkvf.grad[:, :, i]) < 3e-2, (name, rel(qkv.grad[:, :, i], qkvf.grad[:, :, i]))
+    else:
+        assert rel(q.grad, qf.grad) < 3e-2, ("dq", rel(q.grad, qf.grad))
+        assert rel(kv.grad, kvf.grad) < 3e-2, ("dkv", rel(kv.grad, kvf.grad))
 
 
 @pytest.mark.parametrize("b,heads,sq,sk,causal", [(3, 4, 64, 64, False), (2, 3, 512, 512, False), (2, 2, 256, 256, True), (3, 2, 32, 1024, False),

@@ -20,18 +20,18 @@ if pad > 0:
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
 with torch.no_grad():
     for _ in range(2):
-        out = K.attention_core(q, k, v, ids, ids, False, drop_p=drop, seed=1)
+        out = K.attention_core(qkv, None, ids, ids, False, drop_p=drop, seed=1)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     n = 5
     for _ in range(n):
-        out = K.attention_core(q, k, v, ids, ids, False, drop_p=drop, seed=1)
+        out = K.attention_core(qkv, None, ids, ids, False, drop_p=drop, seed=1)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / n
 fl = 4.0 * b * heads * s * s * hn
 qkv.requires_grad_(True)
 q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
-out = K.attention_core(q, k, v, ids, ids, False, drop_p=drop, seed=1)
+out = K.attention_core(qkv, None, ids, ids, False, drop_p=drop, seed=1)
 w = torch.randn_like(out)
 for _ in range(2):
     g = torch.autograd.grad(out, qkv, w, retain_graph=True)
