@@ -4,42 +4,31 @@
 // matrix (reference: transformer.py:283-381 builds it with baddbmm, masked_fill(-10000), softmax, dropout, bmm: 20 GB per layer at
 // 3,200 sequences of 512).  Flash-style online softmax in the "swapped" orientation, so nothing crosses lanes:
 //   S^T[key, q] = K[key, :] . Q[q, :]     MFMA A = K block (LDS), B = Q fragments (registers)   -> a lane owns ONE query column
-//   O^T[d, q]  += V^T[d, key] P^T[key, q]  MFMA A = V^T block (LDS), B = P^T straight from the S^T accumulator registers
+//   O^T[d, q]  += V^T[d, key] P^T[key, q]  MFMA A = V^T gathered from the [key][d] V tile with ds_read_b64_tr_b16, B = P^T straight from the
+//                                          S^T accumulator registers
 // The 32x32 C layout gives lane (q = lane&31, half = lane>>5) the keys {(r&3) + 8(r>>2) + 4*half}; the same key subset is used as
 // the k-index of the second MFMA for both operands, so the accumulators of the first MFMA feed the second without a shuffle.
 // Row max / row sum need one exchange between the two half-waves (lanes q and q+32 share a query).
 // Masks come from token ids (pad id 0) + optional history mask; masked scores are REPLACED by -10000 like the reference.
 // Optional dropout on the probabilities (after normalisation), counter-based: keep(seed, ((b*np+n)*sq+q)*sk+key).
-// Inputs: q [b, sq, np, 64], k [b, sk, np, 64] strided views (last dim contiguous), vT [b, np, 64, sk] (keys contiguous).
+// Inputs: q [b, sq, np, 64], k, v [b, sk, np, 64] strided views (last dim contiguous).
 // Outputs: o [b, sq, np, 64] contiguous, m / l (row max, row sum of exp; fp32 [b, np, sq]) for the backward.
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "rng.h"
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float floatx2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
+#include "attention_common.h"
 
 namespace {
 
-__device__ __forceinline__ uint16_t f2bf(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (uint16_t)(u >> 16);
-}
-
 struct AttnParams {
-    const char *q, *k, *vT;
+    const char *q, *k, *v;
     char *o;
     const long long *ids_q, *ids_k;
     float *m, *l;
     long long q_sb, q_ss, q_sn;   // element strides of q: batch, sequence, head
-    long long k_sb, k_ss, k_sn;
+    long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
     int heads, sq, sk, causal;
     float scale, drop_p;
     uint32_t seed;
@@ -51,7 +40,7 @@ struct AttnParams {
 
 __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
 {
-    // LDS: 2 stages x (K block [64 keys][64 d] 8 KiB + V^T block [64 d][64 keys] 8 KiB), 16-B slots XOR-swizzled by (row & 7)
+    // LDS: 2 stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h)
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
     __shared__ unsigned long long kmask_s[1024];   // key-padding bits, one word per 64-key block (sk <= 65536)
     const int tid = threadIdx.x, lane = tid & 63;
@@ -70,17 +59,20 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     for (int t = 0; t < 4; ++t) qf[t] = *(const bf16x8 *)(qrow + (16 * t + 8 * hi) * 2);
     const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
 
-    // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V^T); wave w moves K piece w and V^T piece w.
-    // piece = 8 rows x 128 B; lane -> (row = lane>>3, slot = lane&7), source slot = slot ^ (row & 7)
-    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ ((lane >> 3) & 7);
+    // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves piece w of each: 8 rows x 128 B,
+    // lane -> (row = 8w + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row)
+    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
-    const char *v_src = p.vT + (((long long)b * p.heads + n) * 64 + prow) * (long long)p.sk * 2 + pslot * 16;  // + key0 * 2
+    const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
     const int nblk = (p.sk + KB - 1) / KB;
     auto issue = [&](int blk, int stage) {                                     // sk % 64 == 0 (checked on the host)
         char *sb = smem + stage * 16384;
-        __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + (long long)(blk * KB + prow) * p.k_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + (long long)(blk * KB) * 2), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+        const long long key = blk * KB + prow;
+        __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
     };
+    uint32_t vtr[2][2];
+    tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
     for (int blk = wave; blk < nblk; blk += 8) {
         const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * KB + lane] != 0);
         if (lane == 0) kmask_s[blk] = w;
@@ -93,7 +85,6 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
         for (int r = 0; r < 16; ++r) oacc[j][r] = 0.f;
     // Softmax bookkeeping in the log2 domain: s2 = score * scale * log2(e), p = exp2(s2 - m2): one FMA + one v_exp per element.
     // A padded query has every score replaced by -10000: per-lane (scale, offset) = (0, -10000 log2 e) does that without a select.
-    const float L2E = 1.4426950408889634f, MASKED2 = -10000.f * 1.4426950408889634f;
     const float sc_q = qpad ? 0.f : p.scale * L2E, c_q = qpad ? MASKED2 : 0.f;
     const bool any_qpad = __builtin_amdgcn_ballot_w64(qpad) != 0ull;
     float mrun = -3.0e38f, lrun = 0.f;
@@ -126,8 +117,7 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
             const int krow = j * 32 + l31;
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
-                const bf16x8 kf = *(const bf16x8 *)(sb + krow * 128 + (((2 * t + hi) ^ (krow & 7)) << 4));
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[t], sacc[j], 0, 0, 0);
+                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc[j], 0, 0, 0);
             }
         }
         // ---- mask, online softmax (this lane: one query, 32 of the 64 keys; its half-wave partner holds the other 32) ----
@@ -198,21 +188,21 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
 #pragma unroll
             for (int w = 0; w < 4; ++w) {
                 const int r0 = (u & 1) * 8 + 2 * w;
-                const floatx2 pr = {sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]};
-                pw[w] = __builtin_bit_cast(uint32_t, __builtin_convertvector(pr, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+                pw[w] = pack_bf16(sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]);
             }
             const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-            // the 8 keys of this lane in k-step u: base + {0,1,2,3, 8,9,10,11} + 4*half, base = (u>>1)*32 + (u&1)*16
-            const int kb0 = (u >> 1) * 32 + (u & 1) * 16 + 4 * hi;
+            // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile) by transpose reads
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int drow = j * 32 + l31;
-                const char *vr = sb + 8192 + drow * 128;
-                const int s0 = kb0 >> 3, s1 = (kb0 + 8) >> 3;                  // 16-B slots holding keys kb0..kb0+3 and kb0+8..kb0+11
-                const uint2 lo = *(const uint2 *)(vr + ((s0 ^ (drow & 7)) << 4) + (kb0 & 7) * 2);
-                const uint2 hi2 = *(const uint2 *)(vr + ((s1 ^ (drow & 7)) << 4) + ((kb0 + 8) & 7) * 2);
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, make_uint4(lo.x, lo.y, hi2.x, hi2.y));
-                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, oacc[j], 0, 0, 0);
+                bf16x8 vt;
+                const uint32_t av[2] = {vtr[j][0] + (uint32_t)(stage * 16384), vtr[j][1] + (uint32_t)(stage * 16384)};
+                switch (u) {
+                case 0: TR_FRAG(vt, av, 0); break;
+                case 1: TR_FRAG(vt, av, 1); break;
+                case 2: TR_FRAG(vt, av, 2); break;
+                default: TR_FRAG(vt, av, 3); break;
+                }
+                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf, oacc[j], 0, 0, 0);
             }
         }
     }
@@ -226,8 +216,8 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = j * 32 + 8 * g + 4 * hi;
-                const uint32_t w0 = (uint32_t)f2bf(oacc[j][4 * g] * inv) | ((uint32_t)f2bf(oacc[j][4 * g + 1] * inv) << 16);
-                const uint32_t w1 = (uint32_t)f2bf(oacc[j][4 * g + 2] * inv) | ((uint32_t)f2bf(oacc[j][4 * g + 3] * inv) << 16);
+                const uint32_t w0 = pack_bf16(oacc[j][4 * g] * inv, oacc[j][4 * g + 1] * inv);
+                const uint32_t w1 = pack_bf16(oacc[j][4 * g + 2] * inv, oacc[j][4 * g + 3] * inv);
                 *(uint2 *)(orow + d) = make_uint2(w0, w1);
             }
         if (hi == 0 && p.m) {
@@ -240,16 +230,16 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
 } // namespace
 
 extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                                   const void *vT, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
+                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
                                    int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream)
 {
-    if (!q || !k || !vT || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7)) return -4;
-    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)vT & 15) || ((uintptr_t)o & 7) || drop_p < 0.f || drop_p >= 1.f) return -1;
+    if (!q || !k || !v || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
+    if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
+    if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7) || drop_p < 0.f || drop_p >= 1.f) return -1;
     AttnParams p;
-    p.q = (const char *)q; p.k = (const char *)k; p.vT = (const char *)vT; p.o = (char *)o;
+    p.q = (const char *)q; p.k = (const char *)k; p.v = (const char *)v; p.o = (char *)o;
     p.ids_q = (const long long *)ids_q; p.ids_k = (const long long *)ids_k; p.m = m; p.l = l;
-    p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn;
+    p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     dim3 grid((sq + QB - 1) / QB, heads, batch);
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, p);

@@ -1,0 +1,70 @@
+// emdr2_amd/csrc/attention_common.h -- tile layout and fragment helpers shared by the fused attention kernels (attention.hip,
+// attention_bwd.hip).  Tiles are [64 rows][64 d] bf16 (128-B rows of eight 16-B granules) filled by LDS-DMA with the granule index XOR
+// f(row), f(row) = (((row >> 1) & 1) << 2) | ((row >> 2) & 3): conflict-free both for row reads (ds_read_b128: 16 consecutive rows, one
+// granule) and for ds_read_b64_tr_b16 transpose reads (4 rows x 4 granules per 32-lane service group; layout pinned by tools/tr_probe.hip).
+#ifndef EMDR2_ATTENTION_COMMON_H
+#define EMDR2_ATTENTION_COMMON_H
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float floatx2 __attribute__((ext_vector_type(2)));
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(1))) const void gptr_t;
+typedef __attribute__((address_space(3))) void lptr_t;
+
+#define L2E 1.4426950408889634f
+#define MASKED2 (-10000.f * 1.4426950408889634f)
+#define TR_READ(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+
+__device__ __forceinline__ int tile_swz(int row) { return (((row >> 1) & 1) << 2) | ((row >> 2) & 3); }
+__device__ __forceinline__ uint32_t pack_bf16(float a, float b)
+{
+    const floatx2 v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));     // v_cvt_pk_bf16_f32 (RNE)
+}
+__device__ __forceinline__ float bf_lo(uint32_t w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf_hi(uint32_t w) { return __uint_as_float(w & 0xffff0000u); }
+
+// Fragment of the row-major global matrix row: 8 bf16 at d = 16 t + 8 hi for t = 0..3 (the B operand of the "swapped" MFMAs)
+__device__ __forceinline__ void load_row_frags(const char *row, int hi, bf16x8 (&f)[4])
+{
+#pragma unroll
+    for (int t = 0; t < 4; ++t) f[t] = *(const bf16x8 *)(row + (16 * t + 8 * hi) * 2);
+}
+
+// Row fragment (MFMA A operand, 8 consecutive d of one tile row) from a swizzled tile
+__device__ __forceinline__ bf16x8 tile_row_frag(const char *tile, int row, int gran)
+{
+    return *(const bf16x8 *)(tile + row * 128 + ((gran ^ tile_swz(row)) << 4));
+}
+
+// Transposed fragments: for the 16-row k-step starting at tile row `rb` (multiple of 16) the lane (col c = jsub*32 + lane&31, half hi) gets rows
+// rb + 4 hi + {0,1,2,3} and rb + 8 + 4 hi + {0,1,2,3} of column c -- the row subset a lane's accumulator registers 8(u&1)..8(u&1)+7 cover.
+// tr_base[jsub][which] holds the lane's byte address for rb = 0.
+__device__ __forceinline__ void tr_addresses(uint32_t tile_lds, int lane, uint32_t (&base)[2][2])
+{
+    const int t = lane & 15, colgrp = (lane >> 4) & 1, hi = lane >> 5;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int col = j * 32 + colgrp * 16 + (t & 3) * 4;
+#pragma unroll
+        for (int w = 0; w < 2; ++w) {
+            const int row = 4 * hi + 8 * w + (t >> 2);
+            base[j][w] = tile_lds + row * 128 + ((((col >> 3) ^ tile_swz(row))) << 4) + (col & 7) * 2;
+        }
+    }
+}
+// k-step u = 0..3 covers tile rows 16 u .. 16 u + 15: tile_swz(row + 16 u) == tile_swz(row) ^ ... only bits (row>>1)&1 and (row>>2)&3 enter, and
+// 16 u changes neither, so the address moves by the plain 2048-byte offset.
+#define TR_FRAG(dst, base, u)                                                              \
+    do {                                                                                   \
+        uint2 lo_, hi_;                                                                    \
+        TR_READ(lo_, (base)[0], (u) * 2048);                                               \
+        TR_READ(hi_, (base)[1], (u) * 2048);                                               \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo_), "+v"(hi_)::"memory");             \
+        dst = __builtin_bit_cast(bf16x8, make_uint4(lo_.x, lo_.y, hi_.x, hi_.y));          \
+    } while (0)
+
+#endif

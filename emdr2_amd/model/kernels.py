@@ -287,14 +287,14 @@ class AttentionCoreFn(torch.autograd.Function):
         scale = 1.0 / math.sqrt(hn)
         m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
-        vT = head_transpose(v, b, sk, heads, hn)
         ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
         if hn == 64 and sk % 64 == 0 and sk <= 65536:
             _native.check(_lib().emdr2_attention_fwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
-                                                     k.stride(2), vT.data_ptr(), ctxo.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq,
+                                                     k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq,
                                                      sk, hn, int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), _sp()),
                           "attention_fwd")
         else:
+            vT = head_transpose(v, b, sk, heads, hn)
             S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
             gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2),
                     k.stride(2), sq * sk, alpha=scale)

@@ -72,11 +72,11 @@ int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, c
 
 /* Fused attention forward for head_dim 64, sk % 64 == 0 (transformer.py:283-381 without the [sq, sk] score matrix): o = dropout(softmax(mask(q k^T
  * scale))) v.  q [b, sq, heads, 64] / k [b, sk, heads, 64] strided views (element strides: batch, sequence, head; last dim contiguous),
- * vT [b, heads, 64, sk], o [b, sq, heads, 64] contiguous, masks from token ids (pad id 0) + causal, masked scores REPLACED by -10000.
+ * v likewise, o [b, sq, heads, 64] contiguous, masks from token ids (pad id 0) + causal, masked scores REPLACED by -10000.
  * m / l (row max and row sum of exp, fp32 [b, heads, sq]) feed the backward.  Dropout keep-bit = keep(seed, row (b*heads+n)*sq+q,
  * column key) of csrc/rng.h (same generator as emdr2_dropout / emdr2_softmax_mask_*).  Returns -4 for shapes it does not cover. */
 int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                        const void *vT, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int head_dim,
+                        const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk, int head_dim,
                         int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream);
 
 /* Fused attention backward for the same shapes (csrc/attention_bwd.hip): dq, dk, dv [b, s, heads, 64] with caller-given batch / sequence element

@@ -42,4 +42,4 @@ for _ in range(n):
 torch.cuda.synchronize()
 dtb = (time.perf_counter() - t0) / n
 print("attention bwd: %.3f ms  %.1f TFLOP/s (2.5x forward flops; incl. scatter of dq/dk/dv into the qkv gradient)" % (dtb * 1e3, 2.5 * fl / dtb / 1e12))
-print("attention fwd b=%d s=%d drop=%.2f pad=%.2f: %.3f ms  %.1f TFLOP/s (incl. V transpose)" % (b, s, drop, pad, dt * 1e3, fl / dt / 1e12))
+print("attention fwd b=%d s=%d drop=%.2f pad=%.2f: %.3f ms  %.1f TFLOP/s " % (b, s, drop, pad, dt * 1e3, fl / dt / 1e12))
