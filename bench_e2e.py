@@ -49,6 +49,9 @@ def main():
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--seq-ret", type=int, default=256)
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (the reference's default, arguments.py)")
+    ap.add_argument("--reindex-rows-per-step", type=int, default=0,
+                    help="BASELINE configs[5]: re-embed this many evidence rows per training step on a side stream into the spare index image "
+                         "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     torch.cuda.set_device(local_rank)
@@ -87,6 +90,12 @@ def main():
     sched = AnnealingLR(2e-5, 10, 1000)
     n_params = sum(p.numel() for p in model.parameters())
 
+    indexer = None
+    if args.reindex_rows_per_step > 0:
+        from emdr2_amd.tasks.openqa.e2eqa.async_indexer import AsyncIndexBuilder
+        indexer = AsyncIndexBuilder(model.retriever_model.context_model, arena, index, S_ret, 101, 102, 0, batch_size=128, log_interval=1 << 30,
+                                    index_reload_interval=1 << 30, batches_per_pump=(args.reindex_rows_per_step + 127) // 128)
+
     g = torch.Generator(device="cuda").manual_seed(99 + rank)
 
     def make_batch():
@@ -106,6 +115,8 @@ def main():
                     labels=labels, mask=(labels != 0).float())
 
     def step():
+        if indexer is not None:
+            indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
         opt.zero_grad()
         lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
@@ -144,7 +155,8 @@ def main():
             "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                    % (B, K, S_ret, S, L, args.rows, args.layers),
                        "global_batch": B * world, "params": n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
-                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss)},
+                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss),
+                       "reindex_rows_per_step": args.reindex_rows_per_step},
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
                          "traffic": None, "flops_per_step_per_gpu": fl, "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"},
         }), flush=True)

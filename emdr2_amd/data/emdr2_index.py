@@ -154,6 +154,37 @@ class HipIndexShard(object):
             torch.cuda.current_stream().synchronize()  # the staging chunk is released next
         return self
 
+    # -- in-HBM refresh (config 5): a second image of the shard is filled while the first keeps serving searches ---------------
+    def begin_refresh(self):
+        """Allocate (once) and clear the spare stripe-tiled image; rows are then written with `refresh_rows` in any order."""
+        if getattr(self, "_spare", None) is None:
+            self._spare = torch.zeros_like(self.tiled)
+            self._spare_emax = torch.zeros_like(self.emax_sq)
+        else:
+            self._spare.zero_(); self._spare_emax.zero_()
+        self._refreshed = 0
+
+    def refresh_rows(self, local_row, rows):
+        """rows fp16 [n, dim] on this device -> spare image rows [local_row, local_row + n), enqueued on the CURRENT stream."""
+        if rows.dtype != torch.float16 or rows.dim() != 2 or rows.shape[1] != self.dim or not rows.is_cuda:
+            raise ValueError("rows must be a CUDA float16 [n, %d] tensor" % self.dim)
+        n = rows.shape[0]
+        if local_row < 0 or local_row + n > self.n_rows:
+            raise ValueError("refresh rows out of range")
+        rows = rows.contiguous()
+        _native.check(self.lib.emdr2_mips_pack_rows(rows.data_ptr(), n, self.dim, local_row, self.n_rows, self._spare.data_ptr(),
+                                                    self._spare_emax.data_ptr(), _native.stream_ptr()), "pack_rows")
+        self._refreshed += n
+
+    def commit_refresh(self):
+        """Swap the images (the reference's `update_index`, emdr2_index.py:232-238, without the disk round trip).  The caller has made the
+        searching stream wait for the stream that wrote the rows."""
+        if getattr(self, "_spare", None) is None or self._refreshed != self.n_rows:
+            raise RuntimeError("refresh incomplete (%d of %d rows)" % (getattr(self, "_refreshed", 0), self.n_rows))
+        self.tiled, self._spare = self._spare, self.tiled
+        self.emax_sq, self._spare_emax = self._spare_emax, self.emax_sq
+        self._refreshed = 0
+
     def set_ids(self, ids):
         ids = torch.as_tensor(np.ascontiguousarray(ids, dtype=np.int32)) if not torch.is_tensor(ids) else ids.to(torch.int32)
         if ids.numel() != self.n_rows:
@@ -286,6 +317,20 @@ class DistributedBruteForceIndex(object):
         if self.embed_data is not None:
             self.embed_data.load_from_file()
         self._set_mips_index()
+
+    # -- in-HBM refresh of this rank's rows (indexer_emdr2.IndexBuilder.build_into_index) -------------------
+    def local_rows(self):
+        """(first global row, one past the last) of this rank's shard; row r holds doc id `ids[r]`."""
+        return self.shard.row_base, self.shard.row_base + self.shard.n_rows
+
+    def begin_refresh(self):
+        self.shard.begin_refresh()
+
+    def refresh_rows(self, global_row, rows):
+        self.shard.refresh_rows(global_row - self.shard.row_base, rows)
+
+    def commit_refresh(self):
+        self.shard.commit_refresh()
 
     def add_embed_data(self, all_embed_data):
         """Upload this rank's row shard (reference: emdr2_index.py:241-266; there: rank 0 uploads

@@ -43,9 +43,14 @@ class PreComputedEvidenceDocsRetriever(object):
                                                      process_group=self.process_group)
         self._barrier()
 
-    def update_evidence_embedding(self):
-        """Reload the index from --embedding-path after an indexer job (emdr2_model.py:426-432)."""
-        self.mips_index.update_index()
+    def update_evidence_embedding(self, from_refresh=False):
+        """Swap in new evidence embeddings after an indexer job (emdr2_model.py:426-432): reload --embedding-path like the reference, or
+        (`from_refresh`) commit the image an in-HBM refresh has just finished (indexer_emdr2.IndexBuilder.build_into_index,
+        async_indexer.AsyncIndexBuilder.maybe_swap do this themselves)."""
+        if from_refresh:
+            self.mips_index.commit_refresh()
+        else:
+            self.mips_index.update_index()
         self._barrier()
 
     def _barrier(self):

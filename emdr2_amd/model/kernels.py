@@ -128,7 +128,8 @@ class _WeightCache(object):
     def get(self, p, kind, build):
         cache = p.__dict__.setdefault("_emdr2_cache", {})
         ent = cache.get(kind)
-        stamp = (p._version, self.epoch)
+        # a frozen parameter (weight snapshot of the side-stream indexer) is never touched by the optimizer: ignore the epoch
+        stamp = (p._version, -1 if p.__dict__.get("_emdr2_frozen") else self.epoch)
         if ent is None or ent[0] != stamp:
             ent = (stamp, build())
             cache[kind] = ent
