@@ -30,6 +30,10 @@ SIGNATURES = {
     "emdr2_mips_exact_workspace_bytes": (_i32, [_i64, _i32, ctypes.POINTER(_sz)]),
     "emdr2_mips_search_exact": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "emdr2_mips_merge": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "emdr2_mips_search_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_exact_workspace_bytes_f32": (_i32, [_i64, _i32, ctypes.POINTER(_sz)]),
+    "emdr2_mips_search_exact_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_merge_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "emdr2_mips_debug_scores": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "emdr2_mips_set_timing": (_i32, [_i32]),
     "emdr2_mips_timing_collect": (_i32, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i64), _i32, ctypes.POINTER(_i32)]),

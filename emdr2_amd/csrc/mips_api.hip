@@ -121,10 +121,10 @@ static int variant_for(int nq) { return nq <= 128 ? 2 : (nq <= 256 ? 1 : 0); }
 static const int kBM[3] = {128, 256, 512};
 static const int kBN[3] = {512, 256, 128};
 
-int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
-                      const void *queries, int n_q, int k, const int32_t *ids, void *out_dist, int32_t *out_idx,
-                      int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
-                      emdr2_stream_t stream_)
+static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
+                       const void *queries, int n_q, int k, const int32_t *ids, void *out_dist, int32_t *out_idx,
+                       int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                       emdr2_stream_t stream_, int f32)
 {
     if (!tiled || !emax_sq || !queries || !out_dist || !out_idx || !out_row || !out_flags || !workspace) return EMDR2_E_BADARG;
     if (n_q < 1 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
@@ -218,7 +218,8 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
         fp.qnorm = w.qnorm;
         fp.emax_sq = emax_sq;
         fp.ids = ids;
-        fp.out_dist = (uint16_t *)out_dist + (size_t)q0 * k;
+        fp.out_dist = f32 ? (void *)((float *)out_dist + (size_t)q0 * k) : (void *)((uint16_t *)out_dist + (size_t)q0 * k);
+        fp.f32 = f32;
         fp.out_idx = out_idx + (size_t)q0 * k;
         fp.out_row = out_row + (size_t)q0 * k;
         fp.flags = out_flags + q0;
@@ -232,6 +233,60 @@ int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_ba
         if ((rc = mips_launch_finalize(fp, stream))) return rc;
     }
     return EMDR2_OK;
+}
+
+int emdr2_mips_search(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
+                      const void *queries, int n_q, int k, const int32_t *ids, void *out_dist, int32_t *out_idx,
+                      int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                      emdr2_stream_t stream)
+{
+    return search_impl(tiled, n_rows, dim, row_base, emax_sq, queries, n_q, k, ids, out_dist, out_idx, out_row, out_flags, workspace,
+                       workspace_bytes, stream, 0);
+}
+
+int emdr2_mips_search_f32(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
+                          const void *queries, int n_q, int k, const int32_t *ids, float *out_dist, int32_t *out_idx,
+                          int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                          emdr2_stream_t stream)
+{
+    return search_impl(tiled, n_rows, dim, row_base, emax_sq, queries, n_q, k, ids, out_dist, out_idx, out_row, out_flags, workspace,
+                       workspace_bytes, stream, 1);
+}
+
+int emdr2_mips_exact_workspace_bytes_f32(int64_t n_rows, int n_sel, size_t *bytes)
+{
+    if (!bytes || n_rows < 1 || n_sel < 0) return EMDR2_E_BADARG;
+    *bytes = align_up((size_t)8 * (size_t)n_rows * sizeof(uint32_t), 256);
+    return EMDR2_OK;
+}
+
+int emdr2_mips_search_exact_f32(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const void *queries,
+                                int n_q, const int32_t *sel, int n_sel, int k, const int32_t *ids, float *out_dist,
+                                int32_t *out_idx, int64_t *out_row, uint32_t *out_flags, void *workspace,
+                                size_t workspace_bytes, emdr2_stream_t stream_)
+{
+    if (!tiled || !queries || !sel || !out_dist || !out_idx || !out_row || !out_flags || !workspace) return EMDR2_E_BADARG;
+    if (n_q < 1 || n_sel < 0 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
+    if (workspace_bytes < (size_t)8 * (size_t)n_rows * sizeof(uint32_t)) return EMDR2_E_WORKSPACE;
+    hipStream_t stream = (hipStream_t)stream_;
+    for (int b = 0; b < n_sel; b += 8) {
+        const int nb = (n_sel - b) < 8 ? (n_sel - b) : 8;
+        int rc;
+        if ((rc = mips_launch_exact_scores_f32((const char *)tiled, n_rows, dim, (const uint16_t *)queries, sel + b, nb,
+                                               (uint32_t *)workspace, stream)))
+            return rc;
+        if ((rc = mips_launch_exact_select_f32((const uint32_t *)workspace, n_rows, row_base, sel + b, nb, k, ids, out_dist, out_idx,
+                                               out_row, out_flags, stream)))
+            return rc;
+    }
+    return EMDR2_OK;
+}
+
+int emdr2_mips_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
+                         float *out_dist, int32_t *out_idx, int64_t *out_row, emdr2_stream_t stream)
+{
+    if (!dist_in || !idx_in || !row_in || !out_dist || !out_idx || !out_row || n_shards < 1 || n_q < 1 || k < 1) return EMDR2_E_BADARG;
+    return mips_launch_merge_f32(dist_in, idx_in, row_in, n_shards, n_q, k, out_dist, out_idx, out_row, (hipStream_t)stream);
 }
 
 int emdr2_mips_exact_workspace_bytes(int64_t n_rows, int n_sel, size_t *bytes)

@@ -233,7 +233,8 @@ int mips_launch_select(uint2 *cand, unsigned *count, float *tau, unsigned *flags
 // finalize: exact integer re-scoring of <= kp candidates, canonical (fp16 score desc, row asc)
 // order, proof that no pruned row can enter the top-k, output
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint16_t exact_score_wave(const char *e_tiled, int64_t row, const uint16_t *qrow, int nseg, int lane)
+__device__ __forceinline__ void exact_dot_wave(const char *e_tiled, int64_t row, const uint16_t *qrow, int nseg, int lane, int64_t &lo_out,
+                                               int64_t &hi_out)
 {
     int64_t lo = 0, hi = 0;
     for (int seg = lane; seg < nseg; seg += 64) {
@@ -246,9 +247,8 @@ __device__ __forceinline__ uint16_t exact_score_wave(const char *e_tiled, int64_
             exact_mac(lo, hi, half_fix((uint16_t)(ew[j] >> 16)), half_fix((uint16_t)(qw[j] >> 16)));
         }
     }
-    lo = wave_sum_i64(lo);
-    hi = wave_sum_i64(hi);
-    return fixed_to_half(lo, hi);
+    lo_out = wave_sum_i64(lo);
+    hi_out = wave_sum_i64(hi);
 }
 
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
@@ -264,8 +264,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
 
     for (unsigned j = wave; j < cnt; j += 4) {
         const unsigned row = cand[j].y;
-        const uint16_t h = exact_score_wave(p.e_tiled, (int64_t)row, qrow, nseg, lane);
-        if (lane == 0) fkey[j] = ((uint64_t)h16_order(h) << 32) | (uint64_t)(0xffffffffu - row);
+        int64_t lo, hi;
+        exact_dot_wave(p.e_tiled, (int64_t)row, qrow, nseg, lane, lo, hi);
+        const uint32_t ord = p.f32 ? f32_order(fixed_to_float(lo, hi)) : h16_order(fixed_to_half(lo, hi));
+        if (lane == 0) fkey[j] = ((uint64_t)ord << 32) | (uint64_t)(0xffffffffu - row);
     }
     if (tid == 0) sh_kth = 0;
     __syncthreads();
@@ -278,7 +280,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
         if (rank < kk) {
             const uint32_t row = 0xffffffffu - (uint32_t)mine;
             const size_t o = (size_t)q * p.k + rank;
-            p.out_dist[o] = h16_unorder((uint32_t)(mine >> 32));
+            if (p.f32) ((float *)p.out_dist)[o] = f32_unorder((uint32_t)(mine >> 32));
+            else ((uint16_t *)p.out_dist)[o] = h16_unorder((uint32_t)(mine >> 32));
             p.out_row[o] = p.row_base + (int64_t)row;
             p.out_idx[o] = p.ids ? p.ids[row] : (int32_t)(p.row_base + (int64_t)row);
             if (rank == kk - 1) sh_kth = (uint32_t)(mine >> 32);
@@ -286,7 +289,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
     }
     for (unsigned j = kk + tid; j < (unsigned)p.k; j += 256) { // shard holds fewer than k rows
         const size_t o = (size_t)q * p.k + j;
-        p.out_dist[o] = 0xfc00; p.out_row[o] = -1; p.out_idx[o] = -1;
+        if (p.f32) ((float *)p.out_dist)[o] = -INFINITY; else ((uint16_t *)p.out_dist)[o] = 0xfc00;
+        p.out_row[o] = -1; p.out_idx[o] = -1;
     }
     __syncthreads();
     if (tid == 0 && p.n_rows > (int64_t)cnt) {
@@ -297,7 +301,8 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
         if (ok) {
             const float eps = (float)p.dim * 2.3841858e-07f /* 2^-22 */ * p.qnorm[q] * (sqrtf(*p.emax_sq) * 1.001f);
             const float bound = p.tau[q] + eps * 1.0001f;
-            ok = h16_order(f32_to_h16_roundup(bound)) < sh_kth;
+            // fp32 mode: a pruned row's exact score is <= bound (a float), so its RNE_fp32 is <= bound as well
+            ok = (p.f32 ? f32_order(bound) : h16_order(f32_to_h16_roundup(bound))) < sh_kth;
         }
         if (!ok) atomicOr(&p.flags[q], 1u);
     }
@@ -358,6 +363,54 @@ int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int6
     if (n_shards * k > MERGE_MAX) return -4;
     hipLaunchKernelGGL(merge_kernel, dim3(n_q), dim3(256), 0, stream, dist_in, idx_in, row_in, n_shards, n_q, k, out_dist, out_idx,
                        out_row);
+    return CHECK_LAUNCH();
+}
+
+// fp32-score twin: key = (f32 order : 32 | ~row : 32); global rows < 2^32
+__global__ void __launch_bounds__(256) merge_f32_kernel(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,
+                                                        int k, float *out_dist, int32_t *out_idx, int64_t *out_row)
+{
+    __shared__ uint64_t key[MERGE_MAX];
+    __shared__ unsigned nvalid;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = n_shards * k;
+    if (tid == 0) nvalid = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int s = i / k, j = i - s * k;
+        const size_t src = ((size_t)s * n_q + q) * k + j;
+        const int64_t row = row_in[src];
+        uint64_t kv = 0;
+        if (row >= 0) {
+            kv = ((uint64_t)f32_order(dist_in[src]) << 32) | (uint64_t)(0xffffffffu - (uint32_t)row);
+            atomicAdd(&nvalid, 1u);
+        }
+        key[i] = kv;
+    }
+    __syncthreads();
+    const unsigned nv = nvalid;
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t mine = key[i];
+        if (mine == 0) continue;
+        unsigned rank = 0;
+        for (int t = 0; t < n; ++t) rank += (key[t] > mine);
+        if (rank < (unsigned)k) {
+            const int s = i / k, j = i - s * k;
+            const size_t src = ((size_t)s * n_q + q) * k + j, o = (size_t)q * k + rank;
+            out_dist[o] = dist_in[src]; out_idx[o] = idx_in[src]; out_row[o] = row_in[src];
+        }
+    }
+    for (unsigned j = nv + tid; j < (unsigned)k; j += 256) {
+        const size_t o = (size_t)q * k + j;
+        out_dist[o] = -INFINITY; out_idx[o] = -1; out_row[o] = -1;
+    }
+}
+
+int mips_launch_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k, float *out_dist,
+                          int32_t *out_idx, int64_t *out_row, hipStream_t stream)
+{
+    if (n_shards * k > MERGE_MAX) return -4;
+    hipLaunchKernelGGL(merge_f32_kernel, dim3(n_q), dim3(256), 0, stream, dist_in, idx_in, row_in, n_shards, n_q, k, out_dist, out_idx, out_row);
     return CHECK_LAUNCH();
 }
 
@@ -509,6 +562,152 @@ int mips_launch_exact_select(const uint16_t *hkeys, int64_t n_rows, int64_t row_
                              unsigned *flags, hipStream_t stream)
 {
     hipLaunchKernelGGL(exact_select_kernel, dim3(n_sel), dim3(XS_THREADS), 0, stream, hkeys, n_rows, row_base, sel, k, ids, out_dist,
+                       out_idx, out_row, flags);
+    return CHECK_LAUNCH();
+}
+
+// ------------------------------------------------------------------------------------------------
+// all-exact fallback, fp32-score mode: 32-bit ordered keys, four-level radix threshold, same ordered collection
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) exact_scores_f32_kernel(const char *__restrict__ e_tiled, int64_t n_rows, int dim,
+                                                               const uint16_t *__restrict__ queries, const int32_t *__restrict__ sel, int n_sel,
+                                                               uint32_t *__restrict__ keys)
+{
+    extern __shared__ int qfix[]; // [n_sel][dim] packed (mant << 8) | shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < n_sel * dim; i += 256) {
+        const int f = i / dim, d = i - f * dim;
+        const HalfFix hf = half_fix(queries[(size_t)sel[f] * dim + d]);
+        qfix[i] = (hf.mant << 8) | hf.shift;
+    }
+    __syncthreads();
+    const int nseg = dim / 8;
+    for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < n_rows; row += (int64_t)gridDim.x * 4) {
+        int64_t lo[XQ], hi[XQ];
+#pragma unroll
+        for (int f = 0; f < XQ; ++f) { lo[f] = 0; hi[f] = 0; }
+        for (int seg = lane; seg < nseg; seg += 64) {
+            const uint4 ev = *(const uint4 *)(e_tiled + tiled_seg_offset(row, seg, nseg >> 2));
+            const uint32_t ew[4] = {ev.x, ev.y, ev.z, ev.w};
+            HalfFix ef[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ef[2 * j] = half_fix((uint16_t)(ew[j] & 0xffff)); ef[2 * j + 1] = half_fix((uint16_t)(ew[j] >> 16)); }
+#pragma unroll
+            for (int f = 0; f < XQ; ++f) {
+                if (f < n_sel) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int pq = qfix[f * dim + seg * 8 + j];
+                        HalfFix qf; qf.mant = pq >> 8; qf.shift = pq & 0xff;
+                        exact_mac(lo[f], hi[f], ef[j], qf);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int f = 0; f < XQ; ++f) {
+            if (f < n_sel) {
+                const int64_t l = wave_sum_i64(lo[f]), h = wave_sum_i64(hi[f]);
+                if (lane == 0) keys[(size_t)f * n_rows + row] = f32_order(fixed_to_float(l, h));
+            }
+        }
+    }
+}
+
+int mips_launch_exact_scores_f32(const char *e_tiled, int64_t n_rows, int dim, const uint16_t *queries, const int32_t *sel, int n_sel,
+                                 uint32_t *keys, hipStream_t stream)
+{
+    if (n_sel > XQ) return -1;
+    int64_t nb = (n_rows + 3) / 4;
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(exact_scores_f32_kernel, dim3((unsigned)nb), dim3(256), (size_t)n_sel * dim * sizeof(int), stream, e_tiled, n_rows, dim,
+                       queries, sel, n_sel, keys);
+    return CHECK_LAUNCH();
+}
+
+__global__ void __launch_bounds__(XS_THREADS) exact_select_f32_kernel(const uint32_t *__restrict__ keys, int64_t n_rows, int64_t row_base,
+                                                                      const int32_t *__restrict__ sel, int k, const int32_t *__restrict__ ids,
+                                                                      float *out_dist, int32_t *out_idx, int64_t *out_row, unsigned *flags)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sh_digit, sh_need, sh_above, sh_wsum[XS_THREADS / 64];
+    __shared__ uint64_t okey[128];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const uint32_t *hk = keys + (size_t)f * n_rows;
+    const unsigned keff = (int64_t)k < n_rows ? (unsigned)k : (unsigned)n_rows;
+
+    // radix threshold, most significant byte first: after level L the k-th key is known to start with `prefix`
+    uint32_t prefix = 0;
+    unsigned need = keff;
+    for (int level = 3; level >= 0; --level) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const int sh = level * 8;
+        for (int64_t i = tid; i < n_rows; i += XS_THREADS) {
+            const uint32_t v = hk[i];
+            if (level == 3 || (v >> (sh + 8)) == (prefix >> (sh + 8))) atomicAdd(&hist[(v >> sh) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) pick_digit(hist, need, &sh_digit, &sh_need);
+        __syncthreads();
+        prefix |= sh_digit << sh;
+        need = sh_need;
+        __syncthreads();
+    }
+    const uint32_t T = prefix;                  // k-th key
+    const unsigned need_eq = need;              // how many rows with key == T belong to the top-k
+    const unsigned n_above = keff - need_eq;
+    if (tid == 0) sh_above = 0;
+    __syncthreads();
+
+    unsigned eq_done = 0;
+    for (int64_t base = 0; base < n_rows; base += (int64_t)XS_THREADS * XS_R) {
+        const int64_t r0 = base + (int64_t)tid * XS_R;
+        unsigned eqm = 0, mycnt = 0;
+#pragma unroll
+        for (int j = 0; j < XS_R; ++j) {
+            const int64_t r = r0 + j;
+            const uint32_t v = r < n_rows ? hk[r] : 0;
+            if (r < n_rows && v > T) { const unsigned s = atomicAdd(&sh_above, 1u); okey[s] = ((uint64_t)v << 32) | (uint64_t)(0xffffffffu - (uint32_t)r); }
+            if (r < n_rows && v == T) { eqm |= 1u << j; ++mycnt; }
+        }
+        unsigned incl = mycnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) { const unsigned t = __shfl_up(incl, o); if (lane >= o) incl += t; }
+        if (lane == 63) sh_wsum[wave] = incl;
+        __syncthreads();
+        unsigned woff = 0, total = 0;
+        for (int w = 0; w < XS_THREADS / 64; ++w) { const unsigned s = sh_wsum[w]; if (w < wave) woff += s; total += s; }
+        unsigned rank = eq_done + woff + incl - mycnt;
+#pragma unroll
+        for (int j = 0; j < XS_R; ++j)
+            if (eqm & (1u << j)) { if (rank < need_eq) okey[n_above + rank] = ((uint64_t)T << 32) | (uint64_t)(0xffffffffu - (uint32_t)(r0 + j)); ++rank; }
+        eq_done += total;
+        __syncthreads();
+    }
+    __syncthreads();
+    const int qi = sel[f];
+    if ((unsigned)tid < keff) {
+        const uint64_t mine = okey[tid];
+        unsigned rank = 0;
+        for (unsigned i = 0; i < keff; ++i) rank += (okey[i] > mine);
+        const uint32_t row = 0xffffffffu - (uint32_t)mine;
+        const size_t o = (size_t)qi * k + rank;
+        out_dist[o] = f32_unorder((uint32_t)(mine >> 32));
+        out_row[o] = row_base + (int64_t)row;
+        out_idx[o] = ids ? ids[row] : (int32_t)(row_base + (int64_t)row);
+    }
+    for (unsigned j = keff + tid; j < (unsigned)k; j += XS_THREADS) {
+        const size_t o = (size_t)qi * k + j;
+        out_dist[o] = -INFINITY; out_row[o] = -1; out_idx[o] = -1;
+    }
+    if (tid == 0) flags[qi] = 0;
+}
+
+int mips_launch_exact_select_f32(const uint32_t *keys, int64_t n_rows, int64_t row_base, const int32_t *sel, int n_sel, int k,
+                                 const int32_t *ids, float *out_dist, int32_t *out_idx, int64_t *out_row, unsigned *flags, hipStream_t stream)
+{
+    hipLaunchKernelGGL(exact_select_f32_kernel, dim3(n_sel), dim3(XS_THREADS), 0, stream, keys, n_rows, row_base, sel, k, ids, out_dist,
                        out_idx, out_row, flags);
     return CHECK_LAUNCH();
 }

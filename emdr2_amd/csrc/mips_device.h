@@ -104,6 +104,30 @@ __device__ __forceinline__ uint16_t fixed_to_half(int64_t lo, int64_t hi)
     return (uint16_t)(sign | (field << 10) | (qq - 1024));
 }
 
+// exact T*2^-48 -> nearest-even fp32 (FaissMIPSIndex-style scores, oracle: fixed48_to_float).  |T| < 2^92 here, far from fp32 overflow;
+// results below 2^-48 * 2^24 are exact (fewer than 24 significant bits).
+__device__ __forceinline__ float fixed_to_float(int64_t lo, int64_t hi)
+{
+    __int128 t = ((__int128)hi << 28) + (__int128)lo;
+    const bool neg = t < 0;
+    unsigned __int128 mag = neg ? (unsigned __int128)(-t) : (unsigned __int128)t;
+    if (mag == 0) return 0.0f;
+    const uint64_t mh = (uint64_t)(mag >> 64), ml = (uint64_t)mag;
+    const int p = mh ? (127 - __clzll(mh)) : (63 - __clzll(ml));
+    int shift = p - 23;
+    uint32_t q;
+    if (shift <= 0) { q = (uint32_t)ml; shift = 0; }
+    else {
+        unsigned __int128 qq = mag >> shift;
+        const unsigned __int128 rem = mag & ((((unsigned __int128)1) << shift) - 1);
+        const unsigned __int128 half = ((unsigned __int128)1) << (shift - 1);
+        if (rem > half || (rem == half && ((uint32_t)qq & 1))) qq += 1;
+        q = (uint32_t)qq;                                  // <= 2^24: exactly representable as float
+    }
+    const float v = ldexpf((float)q, shift - 48);
+    return neg ? -v : v;
+}
+
 // fp32 -> fp16 rounding toward +inf (used only for the conservative validity bound)
 __device__ __forceinline__ uint16_t f32_to_h16_roundup(float f)
 {

@@ -56,15 +56,18 @@ struct FinalizeParams {
     const float *qnorm;
     const float *emax_sq;
     const int32_t *ids;
-    uint16_t *out_dist;
+    void *out_dist;          // uint16 fp16 bits, or float when f32
     int32_t *out_idx;
     int64_t *out_row;
     unsigned *flags;
     int64_t n_rows, row_base;
     int dim, n_q, k, kp;
     unsigned capq;
+    int f32;                 // 1: FaissMIPSIndex-style scores RNE_fp32(exact dot), order (fp32 score desc, row asc)
 };
 int mips_launch_finalize(const FinalizeParams &p, hipStream_t stream);
+int mips_launch_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
+                          float *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
 int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,
                       int k, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
 
@@ -75,3 +78,9 @@ int mips_launch_exact_scores(const char *e_tiled, int64_t n_rows, int dim, const
 int mips_launch_exact_select(const uint16_t *hkeys, int64_t n_rows, int64_t row_base, const int32_t *sel, int n_sel,
                              int k, const int32_t *ids, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row,
                              unsigned *flags, hipStream_t stream);
+
+// fp32-score twins of the all-exact fallback (32-bit ordered keys)
+int mips_launch_exact_scores_f32(const char *e_tiled, int64_t n_rows, int dim, const uint16_t *queries, const int32_t *sel, int n_sel,
+                                 uint32_t *keys /* [n_sel][n_rows] */, hipStream_t stream);
+int mips_launch_exact_select_f32(const uint32_t *keys, int64_t n_rows, int64_t row_base, const int32_t *sel, int n_sel, int k,
+                                 const int32_t *ids, float *out_dist, int32_t *out_idx, int64_t *out_row, unsigned *flags, hipStream_t stream);

@@ -228,6 +228,44 @@ class HipIndexShard(object):
                 self.search_exact(q, sel, k, dist, idx, row, flags)
         return dist, idx, row, flags
 
+    def search_f32(self, queries, k, exact_fallback=True):
+        """FaissMIPSIndex-style scores: queries fp16 [Q, dim] -> (dist fp32 [Q,k] = RNE_fp32(exact dot), idx int32, row int64, flags),
+        order (fp32 score desc, row asc)."""
+        if self._filled != self.n_rows:
+            raise RuntimeError("shard not fully populated (%d of %d rows)" % (self._filled, self.n_rows))
+        if queries.dtype != torch.float16 or queries.dim() != 2 or queries.shape[1] != self.dim or not queries.is_cuda:
+            raise ValueError("queries must be a CUDA float16 [Q, %d] tensor" % self.dim)
+        if not (1 <= k <= _native.MAX_TOPK):
+            raise ValueError("top_k must be in [1, %d]" % _native.MAX_TOPK)
+        import ctypes
+        q = queries.contiguous()
+        nq = q.shape[0]
+        dist = torch.empty((nq, k), dtype=torch.float32, device=self.device)
+        idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+        row = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        if self.n_rows == 0:
+            dist.fill_(float('-inf')); idx.fill_(-1); row.fill_(-1)
+            return dist, idx, row, flags
+        ws = self._workspace(k)
+        ids_ptr = self.ids.data_ptr() if self.ids is not None else None
+        _native.check(self.lib.emdr2_mips_search_f32(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base, self.emax_sq.data_ptr(),
+                                                     q.data_ptr(), nq, k, ids_ptr, dist.data_ptr(), idx.data_ptr(), row.data_ptr(),
+                                                     flags.data_ptr(), ws.data_ptr(), ws.numel(), _native.stream_ptr()), "mips_search_f32")
+        if exact_fallback:
+            sel = torch.nonzero(flags).to(torch.int32).flatten()
+            if sel.numel():
+                nbytes = ctypes.c_size_t()
+                _native.check(self.lib.emdr2_mips_exact_workspace_bytes_f32(self.n_rows, int(sel.numel()), ctypes.byref(nbytes)), "exact_ws_f32")
+                if self._xws is None or self._xws.numel() < nbytes.value:
+                    self._xws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+                sel = sel.contiguous()
+                _native.check(self.lib.emdr2_mips_search_exact_f32(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base, q.data_ptr(), nq,
+                                                                   sel.data_ptr(), int(sel.numel()), k, ids_ptr, dist.data_ptr(), idx.data_ptr(),
+                                                                   row.data_ptr(), flags.data_ptr(), self._xws.data_ptr(), self._xws.numel(),
+                                                                   _native.stream_ptr()), "mips_search_exact_f32")
+        return dist, idx, row, flags
+
     def search_exact(self, q, sel, k, dist, idx, row, flags):
         import ctypes
         nbytes = ctypes.c_size_t()
@@ -267,6 +305,18 @@ def merge_shard_results(dist, idx, row):
     orow = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
     _native.check(lib.emdr2_mips_merge(dist.contiguous().data_ptr(), idx.contiguous().data_ptr(), row.contiguous().data_ptr(),
                                        s, nq, k, od.data_ptr(), oi.data_ptr(), orow.data_ptr(), _native.stream_ptr()), "mips_merge")
+    return od, oi, orow
+
+
+def merge_shard_results_f32(dist, idx, row):
+    """fp32-score twin of merge_shard_results."""
+    lib = _native.lib()
+    s, nq, k = dist.shape
+    od = torch.empty((nq, k), dtype=torch.float32, device=dist.device)
+    oi = torch.empty((nq, k), dtype=torch.int32, device=dist.device)
+    orow = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
+    _native.check(lib.emdr2_mips_merge_f32(dist.contiguous().data_ptr(), idx.contiguous().data_ptr(), row.contiguous().data_ptr(),
+                                           s, nq, k, od.data_ptr(), oi.data_ptr(), orow.data_ptr(), _native.stream_ptr()), "mips_merge_f32")
     return od, oi, orow
 
 
@@ -375,3 +425,49 @@ class DistributedBruteForceIndex(object):
         g_idx = gathered[:, 1].to(torch.int32).contiguous()
         g_row = gathered[:, 2].contiguous()
         return self._merge(g_dist, g_idx, g_row)
+
+
+class FaissMIPSIndex(DistributedBruteForceIndex):
+    """The evaluator's index (reference: emdr2_index.py:103-197: `faiss.IndexFlatIP(embed_size)` under `IndexIDMap`, optionally
+    `index_cpu_to_all_gpus(shard=True, useFloat16=True)`; callers: tasks/openqa/dense_retriever/evaluation/evaluate.py:49,123).
+    Same constructor and methods; `search_mips_index` returns numpy `(distances float32 [Q,k], indices int64 [Q,k])` like faiss, or with
+    `reconstruct=True` the `search_and_reconstruct` triple `(distances, indices, vectors float32 [Q,k,dim])`.
+
+    MI355X-native: the same row-sharded stripe-tiled fp16 image and scan as the training index (faiss's useFloat16 storage), scores
+    = RNE_fp32(exact dot) with order (score desc, row asc) -- the exact-arithmetic restatement of IndexFlatIP (oracle: topk_f32).  Vectors
+    are stored in fp16 (`add_block_data` already produced fp16, emdr2_index.py:61); queries are rounded to fp16 once (the evaluator's
+    queries come out of the fp16 model, so `np.float32(query)` there holds fp16 values).  faiss is absent from /root/reference and
+    unpinned: parity against faiss itself is unpinned; against the oracle it is bit-exact."""
+
+    def add_with_ids(self, embeds, ids):
+        """faiss `IndexIDMap.add_with_ids` (emdr2_index.py:177): float32 / float16 rows keyed by int64 ids."""
+        rows = np.ascontiguousarray(np.asarray(embeds), dtype=np.float16)
+        self.add_arrays(np.asarray(ids), rows)
+
+    def search_mips_index(self, query_embeds, top_k, reconstruct=True):
+        if self.shard is None:
+            raise RuntimeError("MIPS Index is not initialized")
+        q = torch.as_tensor(query_embeds)
+        q = q.to(device=self.shard.device, dtype=torch.float16).contiguous()
+        dist, idx, row, _ = self.shard.search_f32(q, top_k)
+        rank, world = self._world()
+        if world > 1:
+            nq, k = dist.shape
+            packed = torch.stack([dist.view(torch.int32).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
+            gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)
+            torch.distributed.all_gather_into_tensor(gathered, packed, group=self.process_group)
+            gathered = gathered.view(world, 3, nq, k)
+            dist, idx, row = self._merge_f32(gathered[:, 0].to(torch.int32).view(torch.float32).contiguous(),
+                                             gathered[:, 1].to(torch.int32).contiguous(), gathered[:, 2].contiguous())
+        distances = dist.cpu().numpy()
+        indices = idx.to(torch.int64).cpu().numpy()
+        if not reconstruct:
+            return distances, indices
+        if world > 1:
+            raise NotImplementedError("search_and_reconstruct over a sharded index is not used by the reference evaluator")
+        local = (row - self.shard.row_base).clamp(min=0).reshape(-1)
+        vecs = self.shard.rows(local).to(torch.float32).reshape(row.shape[0], row.shape[1], self.embed_size)
+        return distances, indices, vecs.cpu().numpy()
+
+    def _merge_f32(self, dist, idx, row):
+        return merge_shard_results_f32(dist, idx, row)

@@ -117,6 +117,25 @@ int emdr2_mips_merge(const void *dist_in, const int32_t *idx_in, const int64_t *
                      int n_q, int k, void *out_dist, int32_t *out_idx, int64_t *out_row,
                      emdr2_stream_t stream);
 
+/*
+ * FaissMIPSIndex-style twins (reference: megatron/data/emdr2_index.py:103-197 -- faiss.IndexFlatIP over fp16-stored vectors searched
+ * with float32 queries that hold fp16 values, evaluate.py:49,123): score = RNE_fp32(exact dot), order (fp32 score desc, row asc).
+ * Same pipeline, same validity proof in the fp32 key domain, fp32 distances out.  faiss itself is absent from /root/reference and
+ * unpinned (docker/Dockerfile:26-28): parity is against the exact-arithmetic restatement oracle/mips_oracle.c:emdr2_oracle_topk_f32.
+ */
+int emdr2_mips_search_f32(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
+                          const void *queries, int n_q, int k, const int32_t *ids,
+                          float *out_dist, int32_t *out_idx, int64_t *out_row, uint32_t *out_flags,
+                          void *workspace, size_t workspace_bytes, emdr2_stream_t stream);
+int emdr2_mips_exact_workspace_bytes_f32(int64_t n_rows, int n_sel, size_t *bytes);
+int emdr2_mips_search_exact_f32(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const void *queries, int n_q,
+                                const int32_t *sel, int n_sel, int k, const int32_t *ids, float *out_dist, int32_t *out_idx,
+                                int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
+                                emdr2_stream_t stream);
+int emdr2_mips_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
+                         float *out_dist, int32_t *out_idx, int64_t *out_row, emdr2_stream_t stream);
+
+
 /* Diagnostics for tests: fp32 MFMA scores S~[n_q, n_rows] (row-major float) of the scan kernel's
  * arithmetic, for measuring |S~ - exact| against the bound used by the validity check. */
 int emdr2_mips_debug_scores(const void *tiled, int64_t n_rows, int dim, const void *queries, int n_q,
