@@ -1,0 +1,120 @@
+"""Command-line flags of the QA task: the flag set of examples/openqa/emdr2_{nq,trivia,webq}.sh with the reference's names, types and
+defaults (megatron/arguments.py:24-596, tasks/run.py:24-67), so those scripts run against this package unchanged.  Flags that configure
+machinery this build replaces are accepted and recorded but have no effect: --fp16 (bf16 activations + fp32 masters here, no loss
+scaling), --DDP-impl, --distributed-backend, --num-workers, --faiss-use-gpu (the index always lives in HBM), --max-training-rank /
+--async-indexer's extra GPU group (re-indexing runs on a side stream of the trainers), --stale-checkpoint-path, --mmap-warmup.
+Unknown flags raise, like argparse in the reference."""
+import argparse
+import os
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description='EMDR2 on MI355X', allow_abbrev=False)
+    g = p.add_argument_group('network size')
+    g.add_argument('--num-layers', type=int, default=None)
+    g.add_argument('--hidden-size', type=int, default=None)
+    g.add_argument('--num-attention-heads', type=int, default=None)
+    g.add_argument('--kv-channels', type=int, default=None)
+    g.add_argument('--ffn-hidden-size', type=int, default=None)
+    g.add_argument('--max-position-embeddings', type=int, default=None)
+    g.add_argument('--make-vocab-size-divisible-by', type=int, default=128)
+    g.add_argument('--layernorm-epsilon', type=float, default=1e-5)
+    g = p.add_argument_group('regularization')
+    g.add_argument('--attention-dropout', type=float, default=0.1)
+    g.add_argument('--hidden-dropout', type=float, default=0.1)
+    g.add_argument('--weight-decay', type=float, default=0.01)
+    g.add_argument('--clip-grad', type=float, default=1.0)
+    g = p.add_argument_group('training')
+    g.add_argument('--batch-size', type=int, default=None)
+    g.add_argument('--checkpoint-activations', action='store_true')
+    g.add_argument('--seed', type=int, default=1234)
+    g.add_argument('--init-method-std', type=float, default=0.02)
+    g.add_argument('--lr', type=float, default=None)
+    g.add_argument('--lr-decay-style', type=str, default='linear', choices=['linear'])
+    g.add_argument('--lr-decay-iters', type=int, default=None)
+    g.add_argument('--min-lr', type=float, default=0.0)
+    g.add_argument('--warmup', type=float, default=0.01)
+    g.add_argument('--log-interval', type=int, default=100)
+    g.add_argument('--fp16', action='store_true')
+    g.add_argument('--model-parallel-size', type=int, default=1)
+    g.add_argument('--distributed-backend', default='nccl')
+    g.add_argument('--DDP-impl', default='local')
+    g.add_argument('--local_rank', type=int, default=None)
+    g.add_argument('--num-workers', type=int, default=2)
+    g = p.add_argument_group('checkpointing')
+    g.add_argument('--save', type=str, default=None)
+    g.add_argument('--save-interval', type=int, default=None)
+    g.add_argument('--load', type=str, default=None)
+    g.add_argument('--no-save-optim', action='store_true')
+    g.add_argument('--no-load-optim', action='store_true')
+    g.add_argument('--pretrained-t5-load', type=str, default=None)
+    g.add_argument('--pretrained-dpr-load', type=str, default=None)
+    g.add_argument('--stale-checkpoint-path', type=str, default=None)
+    g = p.add_argument_group('validation')
+    g.add_argument('--eval-interval', type=int, default=1000)
+    g.add_argument('--eval-iters', type=int, default=100)
+    g.add_argument('--eval-batch-size', type=int, default=None)
+    g.add_argument('--beam-size', type=int, default=1)
+    g.add_argument('--max-decode-len', type=int, default=512)
+    g = p.add_argument_group('data')
+    g.add_argument('--seq-length', type=int, default=None)
+    g.add_argument('--seq-length-ret', type=int, default=256)
+    g.add_argument('--decoder-seq-length', type=int, default=None)
+    g.add_argument('--vocab-file', type=str, default=None)
+    g.add_argument('--vocab-extra-ids', type=int, default=0)
+    g.add_argument('--tokenizer-type', type=str, default=None, choices=['BertWordPieceLowerCase', 'BertWordPieceCase'])
+    g.add_argument('--data-impl', type=str, default='infer', choices=['mmap', 'infer'])
+    g.add_argument('--mmap-warmup', action='store_true')
+    g.add_argument('--evidence-data-path', type=str, default=None)
+    g.add_argument('--indexed-evidence-data-path', type=str, default=None)
+    g.add_argument('--indexed-title-data-path', type=str, default=None)
+    g.add_argument('--embedding-path', type=str, default=None)
+    g.add_argument('--sample-rate', type=float, default=1.0)
+    g = p.add_argument_group('task (tasks/run.py)')
+    g.add_argument('--task', type=str, required=True)
+    g.add_argument('--epochs', type=int, default=None)
+    g.add_argument('--train-data', nargs='+', default=None)
+    g.add_argument('--valid-data', nargs='*', default=None)
+    g.add_argument('--test-data', nargs='*', default=None)
+    g = p.add_argument_group('emdr2')
+    g.add_argument('--topk-retrievals', type=int, default=100)
+    g.add_argument('--emdr2-training', action='store_true')
+    g.add_argument('--retriever-score-scaling', action='store_true')
+    g.add_argument('--update-retriever', action='store_true')
+    g.add_argument('--allow-trivial-doc', action='store_true')
+    g.add_argument('--disable-retriever-dropout', action='store_true')
+    g.add_argument('--no-query-embedder-training', action='store_true')
+    g.add_argument('--no-context-embedder-training', action='store_true')
+    g.add_argument('--faiss-use-gpu', action='store_true')
+    g.add_argument('--max-training-rank', type=int, default=None)
+    g.add_argument('--async-indexer', action='store_true')
+    g.add_argument('--index-reload-interval', type=int, default=500)
+    g.add_argument('--indexer-batch-size', type=int, default=128)
+    g.add_argument('--indexer-log-interval', type=int, default=1000)
+    g.add_argument('--report-topk-accuracies', nargs='+', type=int, default=[])
+    return p
+
+
+def parse_args(argv=None):
+    args = get_parser().parse_args(argv)
+    args.rank = int(os.getenv('RANK', '0'))
+    args.world_size = int(os.getenv('WORLD_SIZE', '1'))
+    if args.local_rank is None:
+        args.local_rank = int(os.getenv('LOCAL_RANK', '0'))
+    if args.model_parallel_size != 1:
+        raise NotImplementedError("tensor model parallelism is 1 on this path (the reference asserts the same, dualencoder_model.py:15)")
+    for name in ('num_layers', 'hidden_size', 'num_attention_heads', 'max_position_embeddings', 'seq_length', 'decoder_seq_length', 'batch_size', 'lr'):
+        if getattr(args, name) is None:
+            raise ValueError("--%s is required" % name.replace('_', '-'))
+    if args.ffn_hidden_size is None:
+        args.ffn_hidden_size = 4 * args.hidden_size                       # arguments.py:90-91
+    if args.kv_channels is None:
+        args.kv_channels = args.hidden_size // args.num_attention_heads
+    if args.kv_channels * args.num_attention_heads != args.hidden_size:
+        raise ValueError("kv-channels * num-attention-heads must equal hidden-size")
+    if args.eval_batch_size is None:
+        args.eval_batch_size = args.batch_size
+    if args.no_query_embedder_training or args.no_context_embedder_training:
+        raise NotImplementedError("--no-query/context-embedder-training are not used by the shipped scripts and not built")
+    args.iteration = 0
+    return args

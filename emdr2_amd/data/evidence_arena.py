@@ -58,6 +58,45 @@ class EvidenceArena(object):
         self._struct = None
 
     @classmethod
+    def from_indexed(cls, passages_ds, titles_ds, title_keys, device=None):
+        """From the reference's memory-mapped evidence datasets (--indexed-evidence-data-path / --indexed-title-data-path,
+        emdr2_model.py:401-407: `passages_map[doc_id - 1]`, `title_map[doc_id - 1]`) and the evidence file's title strings
+        (`WikiTitleDocMap`, tools/inverted_title_index.py:40-64).  Token arrays are taken as they lie in the .bin files (no per-document
+        Python loop); only the title grouping walks the documents."""
+        p_tok, p_off = passages_ds.flat_tokens()
+        t_tok, t_off = titles_ds.flat_tokens()
+        n = len(p_off) - 1
+        if len(t_off) - 1 != n or len(title_keys) != n:
+            raise ValueError("one title per passage")
+        for a in (p_tok, t_tok):
+            if a.size and (int(a.min()) < 0 or int(a.max()) > 65535):
+                raise ValueError("token ids must fit uint16")
+        self = cls.__new__(cls)
+        groups, order = {}, []
+        for d, key in enumerate(title_keys):
+            g = groups.get(key)
+            if g is None:
+                g = groups[key] = []
+                order.append(key)
+            g.append(d + 1)
+        g_off = np.zeros(len(order) + 1, dtype=np.int64)
+        g_docs = np.empty(n, dtype=np.int32)
+        doc_group = np.zeros(n + 1, dtype=np.int32)
+        doc_pos = np.zeros(n + 1, dtype=np.int32)
+        for gi, key in enumerate(order):
+            docs = groups[key]
+            g_off[gi + 1] = g_off[gi] + len(docs)
+            g_docs[g_off[gi]:g_off[gi + 1]] = docs
+            doc_group[docs] = gi
+            doc_pos[docs] = np.arange(len(docs), dtype=np.int32)
+        self.n_docs = n
+        self.host = dict(passage_tokens=np.ascontiguousarray(p_tok, dtype=np.uint16), passage_off=p_off,
+                         title_tokens=np.ascontiguousarray(t_tok, dtype=np.uint16), title_off=t_off,
+                         group_docs=g_docs, group_off=g_off, doc_group=doc_group, doc_pos=doc_pos)
+        self.device, self.dev, self._struct = device, None, None
+        return self
+
+    @classmethod
     def synthetic(cls, n_docs, seed=1234, vocab=30522, device=None):
         """Synthetic corpus built directly in HBM for benchmarks (passages U[100,160] tokens, titles U[2,8],
         title groups of 1-10 consecutive ids).  No host copy: only `assemble` works on it."""
@@ -118,6 +157,8 @@ class EvidenceArena(object):
         dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.dev = {}
         for k, v in self.host.items():
+            if not v.flags.writeable:
+                v = v.copy()                                   # memory-mapped dataset views are read-only
             t = torch.from_numpy(v.view(np.int16) if v.dtype == np.uint16 else v)
             self.dev[k] = t.to(dev)
         s = _native.EvidenceArenaStruct()

@@ -133,7 +133,14 @@ class EMDR2Model(torch.nn.Module):
             tower.eval()                                                            # emdr2_model.py:69-78
         return self.retriever_model.embed_text(tower, tokens, types)
 
-    def forward(self, query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5, query_ids_t5_len, dec_ids):
+    def forward(self, query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5, query_ids_t5_len, dec_ids,
+                all_query_context_hidden_states=None, all_query_context_ids_unflat=None, topk_log_probs=None):
+        """Training mode: (lm_logits, topk_log_probs, lm_logits_one_context).  Eval mode (emdr2_model.py:211-214): (lm_logits,
+        topk_log_probs, all_query_context_hidden_states [B, K*S, H], all_query_context_ids_unflat [B, K*S]); passing the last two back
+        in skips retrieval and the encoder, which is how the greedy decoder iterates (search_strategy.py:203-213)."""
+        if all_query_context_hidden_states is not None:
+            lm_logits = self.language_model.decode(dec_ids, all_query_context_hidden_states, all_query_context_ids_unflat)
+            return lm_logits, topk_log_probs, all_query_context_hidden_states, all_query_context_ids_unflat
         query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query", self.disable_retriever_dropout)
         with torch.no_grad():                                            # emdr2_model.py:107-115 on the device
             ctx_ids, ctx_types, qext, qone, _, _ = self.evidence_retriever.get_topk_assembled(
@@ -165,14 +172,30 @@ class EMDR2Model(torch.nn.Module):
                     one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
                 finally:
                     K.DROPOUT.pass_id = 0
+        if not self.training:
+            return lm_logits, topk_log_probs, enc, qext.reshape(B, Kk * S)
         return lm_logits, topk_log_probs, one
 
     def state_dict_for_save_checkpoint(self):
-        return {self._language_model_key: self.language_model.state_dict(), self._retriever_model_key: self.retriever_model.state_dict()}
+        """The reference's nested checkpoint dict (emdr2_model.py:217-226; layout in emdr2_amd/checkpointing.py)."""
+        from emdr2_amd import checkpointing
+        return checkpointing.emdr2_state_dict(self)
 
-    def load_state_dict_from_checkpoint(self, state):
-        self.language_model.load_state_dict(state[self._language_model_key])
-        self.retriever_model.load_state_dict(state[self._retriever_model_key])
+    def load_state_dict_from_checkpoint(self, state, strict=True):
+        """emdr2_model.py:228-231 (`load_state_dict` there; torch's flat `load_state_dict` is left untouched here)."""
+        from emdr2_amd import checkpointing
+        checkpointing.load_emdr2_state_dict(self, state, strict)
+        K.WEIGHTS.invalidate()
+
+    def init_state_dict_from_dpr_and_t5(self, pretrained_t5_load, pretrained_dpr_load):
+        """emdr2_model.py:233-247: iteration-0 initialisation from the pre-trained reader and dual encoder."""
+        from emdr2_amd import checkpointing
+        if pretrained_t5_load is None or pretrained_dpr_load is None:
+            import warnings
+            warnings.warn("Pretrained Checkpoints are not found. Initializing from random weights")
+            return
+        checkpointing.load_t5_checkpoint(self.language_model, pretrained_t5_load)
+        checkpointing.load_dualencoder_checkpoint(self.retriever_model, pretrained_dpr_load)
 
 
 def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id):

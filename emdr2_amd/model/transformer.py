@@ -92,6 +92,7 @@ class ParallelAttention(torch.nn.Module):
         self.dense = Linear(h, h, out_std)
         self.hidden_dropout, self.attention_dropout = cfg.hidden_dropout, cfg.attention_dropout
         self._site_attn, self._site_out = K.DROPOUT.new_site(), K.DROPOUT.new_site()
+        self.kv_cache = None            # (encoder_output, kv): set by `cross_kv_cache` during greedy decoding
 
     def forward(self, x, ids_q, ids_k, causal, residual, encoder_output=None):
         b, sq, h = x.shape
@@ -103,7 +104,12 @@ class ParallelAttention(torch.nn.Module):
             ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
         else:
             sk = encoder_output.shape[1]
-            kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
+            if self.kv_cache is not None and self.kv_cache[0] is encoder_output:
+                kv = self.kv_cache[1]                                                     # K/V of the 25,600 encoder tokens, projected once
+            else:
+                kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
+                if self.kv_cache is not None:
+                    self.kv_cache = (encoder_output, kv)
             q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
             ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
@@ -182,6 +188,24 @@ class TransformerLanguageModel(torch.nn.Module):
 
     def decode(self, dec_ids, encoder_output, enc_ids):
         return self.decoder(self.embedding(dec_ids), dec_ids, causal=True, encoder_output=encoder_output, enc_ids=enc_ids)
+
+
+class cross_kv_cache(object):
+    """Context manager: inside it (no_grad, eval) every decoder cross-attention keeps the K/V projection of the encoder output it saw
+    first and reuses it while the same tensor is passed again -- the reference re-projects all K * S encoder tokens for every generated
+    token (search_strategy.py:185-240 calls the full model once per position)."""
+
+    def __init__(self, module):
+        self.attn = [m for m in module.modules() if isinstance(m, ParallelAttention) and m.attention_type != "self"]
+
+    def __enter__(self):
+        for a in self.attn:
+            a.kv_cache = (None, None)
+        return self
+
+    def __exit__(self, *exc):
+        for a in self.attn:
+            a.kv_cache = None
 
 
 class PretrainedBertModel(torch.nn.Module):

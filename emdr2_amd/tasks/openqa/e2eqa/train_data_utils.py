@@ -1,7 +1,10 @@
 """Batch layout of the QA task (reference: tasks/openqa/e2eqa/train_data_utils.py:27-81,128-150 and the collate of
 train_e2eqa.py:51-68).  Host-side int64 list building, unchanged in meaning: question -> [CLS] q [SEP] pad (S_ret),
 answer -> dec_ids = [BOS] a pad, labels = a [EOS] pad, loss_mask (L)."""
+import csv
+from ast import literal_eval
 from collections import OrderedDict
+from copy import deepcopy
 
 import numpy as np
 import torch
@@ -57,3 +60,35 @@ def collate(batch_data):
     t["query_mask_bert"] = torch.tensor(np.array(t["query_mask_bert"]), dtype=torch.int64)
     t["loss_mask"] = torch.tensor(np.array(t["loss_mask"]), dtype=torch.float32)
     return t
+
+
+class OpenQADataset(torch.utils.data.Dataset):
+    """tasks/openqa/e2eqa/train_data_utils.py:105-200: tab-separated `question <TAB> ["answer", ...]` files; uid = -(line number) so it can
+    never collide with a 1-based evidence id; one answer is sampled per access with the dataset's own RandomState(seed)."""
+
+    def __init__(self, task_name, dataset_name, datapaths, tokenizer, max_seq_length, decoder_seq_length, seed=1234):
+        self.np_rng = np.random.RandomState(seed=seed)
+        self.task_name, self.dataset_name, self.tokenizer = task_name, dataset_name, tokenizer
+        self.max_seq_length, self.decoder_seq_length = max_seq_length, decoder_seq_length
+        self.samples = []
+        for datapath in datapaths:
+            self.samples.extend(self.process_samples_from_single_path(datapath))
+
+    def __len__(self):
+        return len(self.samples)
+
+    def __getitem__(self, idx):
+        raw = self.samples[idx]
+        answers = deepcopy(raw['answers'])
+        self.np_rng.shuffle(answers)
+        t = self.tokenizer
+        return build_sample(raw['uid'], t.tokenize(raw['question']), t.tokenize(answers[0]), self.max_seq_length, self.decoder_seq_length,
+                            t.cls, t.sep, t.pad, t.bos_token_id, t.eos_token_id, reference=raw['answers'])
+
+    @staticmethod
+    def process_samples_from_single_path(filename):
+        samples = []
+        with open(filename, 'r') as f:
+            for total, row in enumerate(csv.reader(f, delimiter='\t'), start=1):
+                samples.append({'uid': -total, 'question': row[0], 'answers': literal_eval(row[1])})   # the reference uses eval()
+        return samples

@@ -1,9 +1,16 @@
 """Training-step driver of the QA task (reference: tasks/openqa/e2eqa/train_e2eqa.py:28-41,126-181 and
 megatron/training.py:165-230).  Same forward-step contract: forward_step(batch_or_iter, model) -> (loss, {'lm_loss', 'retriever_loss'})."""
+import time
+
+import numpy as np
 import torch
 
+from emdr2_amd import checkpointing
+from emdr2_amd.global_vars import get_args
 from emdr2_amd.model.emdr2_model import emdr2_loss
-from emdr2_amd.training import allreduce_gradients
+from emdr2_amd.tasks.openqa.e2eqa.eval_utils import exact_match_score, metric_max_over_ground_truths
+from emdr2_amd.tasks.openqa.e2eqa.train_data_utils import collate
+from emdr2_amd.training import AnnealingLR, FusedAdam, allreduce_gradients, get_params_for_weight_decay_optimization
 
 
 def process_batch(batch):
@@ -33,3 +40,194 @@ def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler,
     allreduce_gradients(model, dp_group)
     optimizer.step(lr=lr_scheduler.step())
     return loss_reduced
+
+
+# =====================================================================================================================================
+# the task driver: data loaders, evaluation callbacks, epoch loop (reference: tasks/openqa/e2eqa/train_e2eqa.py:216-621)
+# =====================================================================================================================================
+def print_rank_0(msg):
+    if not torch.distributed.is_initialized() or torch.distributed.get_rank() == 0:
+        print(msg, flush=True)
+
+
+def _dp():
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        return torch.distributed.get_rank(), torch.distributed.get_world_size()
+    return 0, 1
+
+
+def build_data_loader(dataset, batch_size, num_workers, drop_last, shuffle=True):
+    """train_e2eqa.py:343-367: per-rank batches through a DistributedSampler; the collate keeps the 10-key batch of a1."""
+    rank, world = _dp()
+    sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank, shuffle=shuffle)
+    return torch.utils.data.DataLoader(dataset, batch_size=batch_size, sampler=sampler, shuffle=False, num_workers=num_workers,
+                                       drop_last=drop_last, pin_memory=True, collate_fn=collate)
+
+
+def reader_em_score(model, dataloader, topk_retrievals, tokenizer):
+    """train_e2eqa.py:216-283: greedy answers, exact match against every reference answer, de-duplicated over ranks by query uid."""
+    from emdr2_amd.model.search_strategy import SampleOrGreedySearch
+    args = get_args()
+    if args.beam_size != 1:
+        raise NotImplementedError("--beam-size > 1 (BeamSearch) is not built; every shipped script evaluates with --beam-size 1")
+    score_list, quid_list = [], []
+    model.eval()
+    with torch.no_grad():
+        for batch in dataloader:
+            query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, _, _, _, reference = process_batch(batch)
+            search = SampleOrGreedySearch(max_decode_len=args.max_decode_len, bos_id=tokenizer.bos_token_id, eos_id=tokenizer.eos_token_id,
+                                          sample=False, topk_evidence=topk_retrievals)
+            hypothesis = search.generate_output(model, query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len)
+            for quid, ref, hyp in zip(query_uid.tolist(), reference, hypothesis):
+                score_list.append(float(metric_max_over_ground_truths(exact_match_score, tokenizer.decode(hyp), ref)))
+                quid_list.append(quid)
+    model.train()
+    scores = torch.tensor(score_list, dtype=torch.float32, device="cuda")
+    quids = torch.tensor(quid_list, dtype=torch.int64, device="cuda")
+    rank, world = _dp()
+    if world > 1:                                                        # ranks may hold different counts (drop_last False): pad to the max
+        n = torch.tensor([scores.numel()], device="cuda"); nmax = n.clone()
+        torch.distributed.all_reduce(nmax, op=torch.distributed.ReduceOp.MAX)
+        pad = int(nmax.item()) - scores.numel()
+        scores = torch.cat([scores, torch.zeros(pad, device="cuda")]); quids = torch.cat([quids, torch.zeros(pad, dtype=torch.int64, device="cuda")])
+        gs = [torch.empty_like(scores) for _ in range(world)]; gq = [torch.empty_like(quids) for _ in range(world)]
+        torch.distributed.all_gather(gs, scores); torch.distributed.all_gather(gq, quids)
+        scores, quids = torch.cat(gs), torch.cat(gq)
+    score_dict = {q: s for q, s in zip(quids.tolist(), scores.tolist()) if q != 0}     # duplicates (sampler padding) overwrite
+    return {'Exact Match Score': sum(score_dict.values())}, len(score_dict)
+
+
+def validation_loss(model, dataloader, eos_id):
+    """train_e2eqa.py:286-321."""
+    total, score = 0, 0.0
+    model.eval()
+    with torch.no_grad():
+        for batch in dataloader:
+            query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids, labels, loss_mask, _ = process_batch(batch)
+            lm_logits, topk_log_probs, _, _ = model(query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids)
+            _, stats = emdr2_loss(lm_logits, topk_log_probs, None, labels, loss_mask, eos_id)
+            total += 1
+            score += float(stats['lm_loss'])
+    model.train()
+    t = torch.tensor([score, total], dtype=torch.float32, device="cuda")
+    if _dp()[1] > 1:
+        torch.distributed.all_reduce(t)
+    return {'Validation Loss': t[0]}, t[1]
+
+
+def accuracy_func_provider(single_dataset_provider, datapath, tokenizer):
+    """train_e2eqa.py:324-341."""
+    args = get_args()
+    if not datapath:
+        return lambda model, epoch: None
+    dataset = single_dataset_provider(datapath)
+    dataloader = build_data_loader(dataset, args.eval_batch_size, num_workers=args.num_workers, drop_last=False, shuffle=False)
+
+    def metrics_func(model, epoch):
+        print_rank_0('calculating metrics ...')
+        stats, total = reader_em_score(model, dataloader, args.topk_retrievals, tokenizer)
+        fmt = "|total_questions: {}".format(total)
+        for k, v in stats.items():
+            fmt += "|{} = {:.2f}".format(k, (v * 100) / max(total, 1))
+        print_rank_0("epoch:{}{}".format(epoch, fmt))
+        return stats, total
+    return metrics_func
+
+
+def setup_model_and_optimizer(model_provider):
+    """megatron/training.py:136-162: model, FusedAdam over the (decay / no-decay) groups, AnnealingLR, resume or pre-trained init."""
+    args = get_args()
+    model = model_provider()
+    optimizer = FusedAdam(get_params_for_weight_decay_optimization(model), lr=args.lr, weight_decay=args.weight_decay, clip_grad=args.clip_grad)
+    num_iters = args.lr_decay_iters if args.lr_decay_iters is not None else args.train_iters
+    num_iters = max(1, num_iters)
+    lr_scheduler = AnnealingLR(args.lr, warmup_iter=args.warmup * num_iters, total_iters=num_iters, min_lr=args.min_lr)
+    args.iteration = checkpointing.load_checkpoint(args.load, model, None if args.no_load_optim else optimizer, lr_scheduler) if args.load else 0
+    if args.iteration == 0:
+        model.init_state_dict_from_dpr_and_t5(args.pretrained_t5_load, args.pretrained_dpr_load)      # training.py:156-158
+    return model, optimizer, lr_scheduler
+
+
+def _save(iteration, model, optimizer, lr_scheduler):
+    args = get_args()
+    rank, world = _dp()
+    checkpointing.save_checkpoint(args.save, iteration, model, None if args.no_save_optim else optimizer, lr_scheduler, rank=rank,
+                                  barrier=torch.distributed.barrier if world > 1 else None)
+
+
+def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_of_epoch_callback, end_of_epoch_callback2, eos_id, indexer=None):
+    """train_e2eqa.py:413-552.  `indexer`: an AsyncIndexBuilder when --async-indexer (re-indexing on a side stream; the swap at a step
+    boundary replaces the NEW_INDEX_READY / NEW_CHKPT_READY handshake and the reload from disk)."""
+    args = get_args()
+    model.train()
+    start_epoch = args.iteration // args.train_iters_per_epoch
+    start_iteration = args.iteration % args.train_iters_per_epoch
+    iteration = args.iteration
+    sums, t_last = {}, time.time()
+    for epoch in range(start_epoch, args.epochs):
+        print_rank_0('working on epoch {} ...'.format(epoch + 1))
+        train_dataloader.sampler.set_epoch(args.seed + epoch)
+        for iteration_, batch in enumerate(train_dataloader):
+            if iteration_ < start_iteration:
+                continue
+            start_iteration = 0
+            if indexer is not None:
+                indexer.pump()
+            losses = train_step(forward_step, batch, model, optimizer, lr_scheduler, eos_id)
+            iteration += 1
+            if indexer is not None and indexer.maybe_swap(iteration):
+                print_rank_0("Training Group: MIPS Index Updated at iteration {}".format(iteration))
+                if args.save:
+                    _save(iteration, model, optimizer, lr_scheduler)                          # the reference checkpoints at every reload
+            for k, v in losses.items():
+                sums[k] = sums.get(k, 0.0) + v
+            if iteration % args.log_interval == 0:
+                dt = (time.time() - t_last) * 1000.0 / args.log_interval
+                t_last = time.time()
+                msg = ' iteration {:8d}/{:8d} | elapsed time per iteration (ms): {:.1f} | learning rate: {:.3E} |'.format(
+                    iteration, args.train_iters, dt, lr_scheduler.get_lr())
+                for k in sums:
+                    msg += ' {}: {:.6E} |'.format(k, float(sums[k]) / args.log_interval)
+                print_rank_0(msg)
+                sums = {}
+            if args.save and args.save_interval and iteration % args.save_interval == 0:
+                _save(iteration, model, optimizer, lr_scheduler)
+            if args.eval_interval and iteration % args.eval_interval == 0 and end_of_epoch_callback is not None:
+                end_of_epoch_callback(model, iteration)
+                end_of_epoch_callback2(model, iteration)
+        if args.save:
+            _save(iteration, model, optimizer, lr_scheduler)
+        if end_of_epoch_callback is not None:
+            end_of_epoch_callback(model, epoch + 1)
+            end_of_epoch_callback2(model, epoch + 1)
+    return iteration
+
+
+def train(train_valid_datasets_provider, model_provider, forward_step=_cross_entropy_forward_step, end_of_epoch_callback_provider=None,
+          end_of_training_callback_provider=None, eos_id=None, indexer_provider=None):
+    """train_e2eqa.py:555-621."""
+    args = get_args()
+    train_dataloader = None
+    if args.epochs > 0:
+        train_dataset, valid_dataset = train_valid_datasets_provider()
+        train_dataloader = build_data_loader(train_dataset, args.batch_size, args.num_workers, drop_last=True)
+        args.train_iters_per_epoch = len(train_dataloader)
+        args.train_iters = args.epochs * args.train_iters_per_epoch
+    else:
+        args.train_iters_per_epoch, args.train_iters = 1, 0
+    cb1 = cb2 = None
+    if args.epochs > 0 and end_of_epoch_callback_provider is not None:
+        cb1, cb2 = end_of_epoch_callback_provider(args.valid_data), end_of_epoch_callback_provider(args.test_data)
+    model, optimizer, lr_scheduler = setup_model_and_optimizer(model_provider)
+    print_rank_0('done with setups ...')
+    print_rank_0('training ...')
+    if args.epochs > 0 and args.emdr2_training:
+        indexer = indexer_provider(model) if (indexer_provider is not None and args.async_indexer) else None
+        _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, cb1, cb2, eos_id, indexer)
+    results = {}
+    if end_of_training_callback_provider is not None:
+        for name, path in (("validation", args.valid_data), ("test", args.test_data)):
+            if path:
+                results[name] = end_of_training_callback_provider(path)(model, epoch=-1)
+    print_rank_0('done :-)')
+    return model, results

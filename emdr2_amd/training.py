@@ -31,6 +31,14 @@ class AnnealingLR(object):
         self.num_iters += 1
         return self.get_lr()
 
+    def state_dict(self):
+        """learning_rates.py:86-95 (same keys)."""
+        return {'start_lr': self.start_lr, 'warmup_iter': self.warmup_iter, 'num_iters': self.num_iters, 'decay_style': 'linear',
+                'end_iter': self.end_iter, 'min_lr': self.min_lr}
+
+    def load_state_dict(self, sd):
+        self.num_iters = sd['num_iters']
+
 
 class FusedAdam(object):
     """Adam with decoupled weight decay on fp32 masters (apex FusedAdam(adam_w_mode=True) defaults betas (0.9, 0.999), eps 1e-8;
@@ -47,6 +55,21 @@ class FusedAdam(object):
         for g in self.groups:
             for p in g["params"]:
                 p.grad = None
+
+    def state_dict(self):
+        """Moments in parameter order (torch-optimizer style: {'step', 'state': {index: {'exp_avg', 'exp_avg_sq'}}})."""
+        params = [p for g in self.groups for p in g["params"]]
+        return {'step': self.step_count,
+                'state': {i: {'exp_avg': self.state[p][0], 'exp_avg_sq': self.state[p][1]} for i, p in enumerate(params) if p in self.state}}
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.groups for p in g["params"]]
+        self.step_count = sd['step']
+        for i, st in sd['state'].items():
+            p = params[int(i)]
+            self.state[p] = (st['exp_avg'].to(p.device, torch.float32).clone(), st['exp_avg_sq'].to(p.device, torch.float32).clone())
+        from emdr2_amd.model import kernels
+        kernels.DROPOUT.step = self.step_count
 
     def step(self, lr=None):
         lib = _native.lib()

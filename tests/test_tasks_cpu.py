@@ -43,3 +43,49 @@ def test_weight_decay_groups():
             self.input_layernorm = torch.nn.LayerNorm(4)
     groups = get_params_for_weight_decay_optimization(M())
     assert len(groups[0]["params"]) == 1 and len(groups[1]["params"]) == 3 and groups[1]["weight_decay"] == 0.0
+
+
+def test_exact_match_metric_matches_reference_pairs():
+    import json
+    import os
+    from emdr2_amd.tasks.openqa.e2eqa.eval_utils import exact_match_score, metric_max_over_ground_truths
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ckpt_layout.json")))
+    got = [bool(metric_max_over_ground_truths(exact_match_score, h, r)) for h, r in ref["em_pairs"]]
+    assert got == ref["em"]
+
+
+def test_argument_parser_accepts_the_reference_script_flags_and_rejects_unknown_ones():
+    import pytest
+    from emdr2_amd import arguments
+    base = ("--task OPENQA --num-layers 12 --hidden-size 768 --num-attention-heads 12 --kv-channels 64 --ffn-hidden-size 3072 --model-parallel-size 1 "
+            "--train-data a.tsv --valid-data b.tsv --test-data c.tsv --evidence-data-path e --indexed-evidence-data-path x --indexed-title-data-path y "
+            "--save-interval 500 --save s --load s --pretrained-t5-load p --pretrained-dpr-load d --stale-checkpoint-path d --embedding-path e "
+            "--log-interval 20 --eval-interval 500 --eval-iters 10 --weight-decay 1.0e-1 --seq-length 512 --seq-length-ret 256 --decoder-seq-length 32 "
+            "--max-decode-len 32 --max-position-embeddings 512 --fp16 --vocab-file v --num-workers 2 --distributed-backend nccl "
+            "--checkpoint-activations --tokenizer-type BertWordPieceLowerCase --epochs 10 --sample-rate 1.0 --batch-size 8 --eval-batch-size 8 "
+            "--beam-size 1 --lr 2e-5 --warmup 0.01 --DDP-impl local --lr-decay-style linear --max-training-rank 8 --faiss-use-gpu "
+            "--topk-retrievals 50 --emdr2-training --retriever-score-scaling --update-retriever --allow-trivial-doc --async-indexer "
+            "--index-reload-interval 500").split()
+    a = arguments.parse_args(base)
+    assert (a.topk_retrievals, a.hidden_dropout, a.attention_dropout, a.weight_decay, a.clip_grad, a.seed) == (50, 0.1, 0.1, 0.1, 1.0, 1234)
+    assert a.train_data == ["a.tsv"] and a.index_reload_interval == 500 and a.indexer_batch_size == 128 and a.async_indexer
+    with pytest.raises(SystemExit):
+        arguments.parse_args(base + ["--no-such-flag"])
+    with pytest.raises(NotImplementedError):
+        arguments.parse_args(base[:-2] + ["--model-parallel-size", "2"])
+
+
+def test_openqa_dataset_reads_the_reference_file_format(tmp_path):
+    import os
+    from emdr2_amd.tasks.openqa.e2eqa.train_data_utils import OpenQADataset, collate
+    from emdr2_amd.tokenizer import BertWordPieceTokenizer
+    t = BertWordPieceTokenizer(os.path.join(os.path.dirname(__file__), "golden", "tokenizer_vocab.txt"))
+    p = tmp_path / "qa.tsv"
+    p.write_text('who was the first emperor\t["the emperor", "emperor"]\nwhat year did the war end\t["1999"]\n')
+    ds = OpenQADataset("OPENQA", "t", [str(p)], t, 16, 8, seed=1)
+    assert len(ds) == 2 and ds.samples[1]["uid"] == -2 and ds.samples[0]["answers"] == ["the emperor", "emperor"]
+    s = ds[0]
+    assert s["query_uid"] == -1 and s["query_ids_bert"][0] == t.cls and len(s["query_ids_bert"]) == 16 and len(s["dec_ids"]) == 8
+    assert s["dec_ids"][0] == t.bos_token_id and t.eos_token_id in s["labels"] and s["reference"] == ["the emperor", "emperor"]
+    b = collate([ds[0], ds[1]])
+    assert b["query_ids_bert"].shape == (2, 16) and b["loss_mask"].dtype.is_floating_point and b["query_uid"].tolist() == [-1, -2]
