@@ -110,6 +110,56 @@ class OpenRetreivalDataStore(object):
         return ids.astype(np.int32), rows
 
 
+# ---- flat evidence-embedding file --------------------------------------------------------------------------------
+FLAT_MAGIC = b'EMDR2EMB'
+
+
+class FlatEmbeddingFile(object):
+    """`[N, D]` fp16 rows + int32 doc ids in one memory-mappable file, as an alternative to the reference's pickle of N tiny arrays
+    (32 GB, minutes to unpickle per reload).  Layout: 8-byte magic | u32 version = 1 | u32 D | u64 N | int32 ids[N] | pad to 4096 |
+    fp16 rows[N, D].  Row order = the pickle's dict order, so an index built from either file is identical; `from_store` / `to_store`
+    convert in both directions so `--embedding-path` artefacts interoperate with the reference."""
+
+    def __init__(self, path):
+        import struct
+        self.path = path
+        with open(path, 'rb') as f:
+            if f.read(8) != FLAT_MAGIC:
+                raise ValueError("not a flat embedding file: %s" % path)
+            version, self.dim, self.n = struct.unpack('<IIQ', f.read(16))
+            if version != 1:
+                raise ValueError("unsupported flat embedding file version %d" % version)
+        self._ids_off = 24
+        self._rows_off = (self._ids_off + 4 * self.n + 4095) // 4096 * 4096
+        self.ids = np.memmap(path, dtype=np.int32, mode='r', offset=self._ids_off, shape=(self.n,))
+        self.rows = np.memmap(path, dtype=np.float16, mode='r', offset=self._rows_off, shape=(self.n, self.dim))
+
+    @staticmethod
+    def write(path, ids, rows):
+        import struct
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        rows = np.ascontiguousarray(rows, dtype=np.float16)
+        if rows.ndim != 2 or ids.shape != (rows.shape[0],):
+            raise ValueError("ids [N] and rows [N, D] expected")
+        with open(path, 'wb') as f:
+            f.write(FLAT_MAGIC)
+            f.write(struct.pack('<IIQ', 1, rows.shape[1], rows.shape[0]))
+            f.write(ids.tobytes())
+            f.write(b'\0' * ((-f.tell()) % 4096))
+            f.write(rows.tobytes())
+
+    @classmethod
+    def from_store(cls, store, path):
+        ids, rows = store.to_arrays()
+        cls.write(path, ids, rows)
+        return cls(path)
+
+    def to_store(self, embedding_path, rank=0):
+        store = OpenRetreivalDataStore(embedding_path, load_from_path=False, rank=rank)
+        store.add_block_data(self.ids.tolist(), np.asarray(self.rows))
+        return store
+
+
 def shard_bounds(num_rows, world_size):
     """Row range per rank, torch.chunk semantics like the reference's per-device split
     (emdr2_index.py:252-254): equal chunks of ceil(N/W) rows, the last one shorter (possibly empty)."""
@@ -388,6 +438,13 @@ class DistributedBruteForceIndex(object):
         ids, rows = all_embed_data.to_arrays()
         self.add_arrays(ids, rows)
         all_embed_data.clear()
+
+    def add_flat_file(self, flat):
+        """Load this rank's shard straight from a `FlatEmbeddingFile` (memory map -> pinned chunks -> HBM); only the rank's own rows are
+        ever touched on the host."""
+        if isinstance(flat, str):
+            flat = FlatEmbeddingFile(flat)
+        self.add_arrays(flat.ids, flat.rows)
 
     def add_arrays(self, ids, rows):
         if rows.dtype != np.float16 or rows.shape[1] != self.embed_size:

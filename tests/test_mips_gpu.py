@@ -193,3 +193,19 @@ def test_index_class_end_to_end_single_rank():
     od, oi = mo.topk(case["rows"], case["queries"], case["k"], ids=case["ids"])
     assert_bit_identical(dist.cpu().numpy(), idx.cpu().numpy(), od, oi)
     assert len(store.embed_data) == 0      # reference clears the store after upload (emdr2_index.py:263)
+
+
+def test_index_from_flat_embedding_file_equals_index_from_the_pickle_store(tmp_path):
+    from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, FlatEmbeddingFile, OpenRetreivalDataStore
+    case = mips_cases.case_realistic()
+    store = OpenRetreivalDataStore(embedding_path=str(tmp_path / "e.pkl"), load_from_path=False, rank=0)
+    store.add_block_data([int(x) for x in case["ids"]], case["rows"])
+    flat = FlatEmbeddingFile.from_store(store, str(tmp_path / "e.flat"))
+    a = DistributedBruteForceIndex(embed_size=768, embed_data=store, use_gpu=True)
+    b = DistributedBruteForceIndex(embed_size=768, embed_data=None, use_gpu=True)
+    b.add_flat_file(str(tmp_path / "e.flat"))
+    q = torch.from_numpy(case["queries"]).cuda()
+    da, ia = a.search_mips_index(q, case["k"])
+    db, ib = b.search_mips_index(q, case["k"])
+    assert torch.equal(da.view(torch.int16), db.view(torch.int16)) and torch.equal(ia, ib)
+    assert flat.n == case["rows"].shape[0]

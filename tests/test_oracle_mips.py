@@ -119,3 +119,28 @@ def test_fp32accum_port_agrees_except_rounding_boundaries():
     d2, r2 = mo.topk_fp32accum(case["rows"], case["queries"], case["k"])
     assert (d2.view(np.uint16) == d.view(np.uint16)).mean() > 0.995
     assert (r2 == r).mean() > 0.99
+
+
+def test_flat_embedding_file_round_trips_and_converts_to_the_reference_pickle(tmp_path):
+    """flat [N, D] fp16 + ids file <-> the reference's pickle store, same row order."""
+    import numpy as np
+    from emdr2_amd.data.emdr2_index import FlatEmbeddingFile, OpenRetreivalDataStore
+    rng = np.random.default_rng(0)
+    ids = (rng.permutation(100) + 1).astype(np.int64)
+    rows = rng.standard_normal((100, 64)).astype(np.float16)
+    store = OpenRetreivalDataStore(str(tmp_path / "emb.pkl"), load_from_path=False, rank=0)
+    store.add_block_data(ids, rows)
+    flat = FlatEmbeddingFile.from_store(store, str(tmp_path / "emb.flat"))
+    assert flat.n == 100 and flat.dim == 64 and np.array_equal(flat.ids, ids) and np.array_equal(np.asarray(flat.rows), rows)
+    assert flat._rows_off % 4096 == 0
+    back = flat.to_store(str(tmp_path / "emb2.pkl"))
+    assert list(back.embed_data.keys()) == ids.tolist()
+    assert all(np.array_equal(back.embed_data[int(i)], rows[n]) and back.embed_data[int(i)].dtype == np.float16 for n, i in enumerate(ids))
+    back.save_shard(); back.merge_shards_and_save()
+    again = OpenRetreivalDataStore(str(tmp_path / "emb2.pkl"), load_from_path=True)
+    i2, r2 = again.to_arrays()
+    assert np.array_equal(i2, ids.astype(np.int32)) and np.array_equal(r2, rows)
+    import pytest
+    (tmp_path / "bad").write_bytes(b"x" * 64)
+    with pytest.raises(ValueError):
+        FlatEmbeddingFile(str(tmp_path / "bad"))
