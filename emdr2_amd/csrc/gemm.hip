@@ -12,6 +12,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "rng.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -33,6 +34,7 @@ struct GemmParams {
     int gelu, out_f32;
     float drop_p;             // dropout on (acc*alpha + bias [gelu]) before the residual add: bias_dropout_add (transformer.py:397-413)
     uint32_t seed;            // keep bit = emdr2_keep(row_hash(seed, m), n, thr)
+    int tiles_m, tiles_n, order; // order 1: 1-D grid, n-tiles fastest inside a per-XCD contiguous tile range (operand A read once from HBM)
     int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
 
@@ -62,7 +64,18 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     const int l31 = lane & 31, hi = lane >> 5;
     const int swz = (l31 >> 2) & 3;
 
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    int tm = blockIdx.x, tn = blockIdx.y;
+    if (p.order == 1) {
+        // Workgroup ids are dealt round-robin to the 8 XCDs, each with its own L2.  Give every XCD one contiguous range of tiles and walk
+        // it with the n index fastest: the tiles_n workgroups that share an A panel run back to back on the same L2, so A streams from
+        // HBM once instead of tiles_n times (N = 3072: 12 times), and B (a weight matrix) stays L2-resident anyway.
+        const int total = p.tiles_m * p.tiles_n, id = blockIdx.x;
+        const int per = (total + 7) >> 3;
+        int t = (id & 7) * per + (id >> 3);
+        if (t >= total) return;                                        // ragged tail of the last XCD ranges (grid is padded to 8 * per)
+        tm = t / p.tiles_n; tn = t - tm * p.tiles_n;
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
     const int zb = blockIdx.z / p.splitk, zs = blockIdx.z % p.splitk;
     const int b1 = zb / p.batch2, b2 = zb % p.batch2;
     const char *A = p.A + ((long long)b1 * p.sA1 + (long long)b2 * p.sA2) * 2;
@@ -251,8 +264,13 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
         if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_done = true;
     }
-    dim3 grid((p.M + BM - 1) / BM, (p.N + BN - 1) / BN, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(512), LDS, stream, p);
+    GemmParams q = p;
+    q.tiles_m = (p.M + BM - 1) / BM; q.tiles_n = (p.N + BN - 1) / BN;
+    static const int order_env = getenv("EMDR2_GEMM_ORDER") ? atoi(getenv("EMDR2_GEMM_ORDER")) : 1;
+    q.order = (order_env == 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
+    dim3 grid(q.tiles_m, q.tiles_n, batch * p.splitk);
+    if (q.order == 1) grid = dim3(((q.tiles_m * q.tiles_n + 7) / 8) * 8, 1, batch * p.splitk);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(512), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

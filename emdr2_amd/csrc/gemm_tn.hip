@@ -28,6 +28,7 @@ struct TnParams {
     float *C, *colsum;
     long long lda, ldb, ldc;
     int I, J, R, splitk;
+    int tiles_i, tiles_j;
 };
 
 #define TN_STAGES 3
@@ -47,8 +48,16 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(TnParams p)
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, hi = lane >> 5;
     const int t = lane & 15, colgrp = (lane >> 4) & 1;
-    const int i0 = blockIdx.x * 256, j0 = blockIdx.y * 256;
-    const int zs = blockIdx.z;
+    // 1-D grid, XCD-aware: workgroup ids go round-robin to the 8 XCDs (one L2 each); every XCD gets a contiguous range of
+    // (reduction slice, tile) pairs with the tile index fastest, so the tiles_i * tiles_j workgroups that stream the SAME token rows of
+    // dy and x run together on one L2 and both operands leave HBM once per slice.
+    const int tiles = p.tiles_i * p.tiles_j, total = tiles * p.splitk;
+    const int per_xcd = (total + 7) >> 3;
+    const int t_id = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
+    if (t_id >= total) return;
+    const int zs = t_id / tiles, tile = t_id - zs * tiles;
+    const int tj = tile / p.tiles_i, ti = tile - tj * p.tiles_i;
+    const int i0 = ti * 256, j0 = tj * 256;
 
     // fragment addresses: lane -> row (t >> 2) of its group's [4][16] block, column segment (t & 3) * 4
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
@@ -105,7 +114,7 @@ __global__ void __launch_bounds__(512) gemm_tn_kernel(TnParams p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     float csum[2] = {0.f, 0.f};
-    const bool want_colsum = p.colsum && blockIdx.y == 0 && wn == 0;
+    const bool want_colsum = p.colsum && tj == 0 && wn == 0;
 
     issue();
     issue();
@@ -200,7 +209,8 @@ extern "C" int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int
         if (hipFuncSetAttribute((const void *)gemm_tn_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_done = true;
     }
-    dim3 grid((I + 255) / 256, (J + 255) / 256, split_k);
+    p.tiles_i = (I + 255) / 256; p.tiles_j = (J + 255) / 256;
+    dim3 grid((unsigned)(((p.tiles_i * p.tiles_j * split_k + 7) / 8) * 8));
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(512), LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
