@@ -51,11 +51,12 @@ __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + e
 // VEC: bf16 output staged through LDS per wave and written as 16-byte row segments (bias / GELU / pre-activation / residual
 // applied on 8-element vectors); otherwise (fp32 output, split-K atomics, unaligned leading dimensions) the scalar epilogue.
 template <int WM, int WN, bool VEC>
-__global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
+__global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
 {
     constexpr int BM = WM * 64, BN = WN * 128;
     constexpr int A_STAGE = BM * 64, B_STAGE = BN * 64, STAGE = A_STAGE + B_STAGE;
-    constexpr int A_PW = BM / 128, B_PW = BN / 128, PPW = A_PW + B_PW;
+    constexpr int NW = WM * WN;                                       // waves per workgroup: each owns a 64 x 128 output sub-tile
+    constexpr int A_PW = BM / (16 * NW), B_PW = BN / (16 * NW), PPW = A_PW + B_PW;   // 1-KiB DMA pieces per wave and stage
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -96,13 +97,13 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     const char *b_src[B_PW];
 #pragma unroll
     for (int j = 0; j < A_PW; ++j) {
-        const int r = (wave + 8 * j) * 16 + prow;                   // row inside the tile
+        const int r = (wave + NW * j) * 16 + prow;                  // row inside the tile
         int gm = m0 + r; if (gm >= p.M) gm = p.M - 1;               // overhang rows re-read the last row (never stored)
         a_src[j] = A + ((long long)gm * p.lda + ((pslot ^ ((r >> 2) & 3)) << 3)) * 2;
     }
 #pragma unroll
     for (int j = 0; j < B_PW; ++j) {
-        const int r = (wave + 8 * j) * 16 + prow;
+        const int r = (wave + NW * j) * 16 + prow;
         int gn = n0 + r; if (gn >= p.N) gn = p.N - 1;
         b_src[j] = B + ((long long)gn * p.ldb + ((pslot ^ ((r >> 2) & 3)) << 3)) * 2;
     }
@@ -118,10 +119,10 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
         char *sb = smem + pf_stage * STAGE;
 #pragma unroll
         for (int j = 0; j < A_PW; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t *)(a_src[j] + c * 64), (lptr_t *)(sb + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(a_src[j] + c * 64), (lptr_t *)(sb + (wave + NW * j) * 1024), 16, 0, 0);
 #pragma unroll
         for (int j = 0; j < B_PW; ++j)
-            __builtin_amdgcn_global_load_lds((gptr_t *)(b_src[j] + c * 64), (lptr_t *)(sb + A_STAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(b_src[j] + c * 64), (lptr_t *)(sb + A_STAGE + (wave + NW * j) * 1024), 16, 0, 0);
         ++pf_c;
         pf_stage = (pf_stage == GNST - 1) ? 0 : pf_stage + 1;
     };
@@ -138,7 +139,8 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
     issue();
     int cs = 0;
     for (int c = 0; c < nch; ++c) {
-        if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -172,6 +174,17 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
         for (int j = 0; j < 8; ++j) bv[j] = (p.bias && ncol + j < p.N) ? p.bias[ncol + j] : 0.f;
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
+            // residual rows of this half: all eight 16-byte loads go out BEFORE the LDS round trip, so their HBM latency overlaps the
+            // staging instead of serialising one load per 4-row step (that chain cost more than the whole k-loop at K = 768)
+            uint4 rr[8];
+            if (p.R) {
+#pragma unroll
+                for (int g = 0; g < 8; ++g) {
+                    const int m = m0 + wm * 64 + mi * 32 + g * 4 + rsub;
+                    rr[g] = make_uint4(0, 0, 0, 0);
+                    if (m < p.M && ncol < p.N) rr[g] = *(const uint4 *)((const uint16_t *)p.R + coff + (long long)m * p.ldc + ncol);
+                }
+            }
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -209,8 +222,7 @@ __global__ void __launch_bounds__(512) gemm_nt_kernel(GemmParams p)
                         }
                     }
                     if (p.R) {
-                        const uint4 rr = *(const uint4 *)((const uint16_t *)p.R + o);
-                        const uint32_t rw[4] = {rr.x, rr.y, rr.z, rr.w};
+                        const uint32_t rw[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};
 #pragma unroll
                         for (int j = 0; j < 4; ++j) { v[2 * j] += bf16_to_f32((uint16_t)(rw[j] & 0xffff)); v[2 * j + 1] += bf16_to_f32((uint16_t)(rw[j] >> 16)); }
                     }
@@ -257,7 +269,7 @@ template <int WM, int WN, bool VEC>
 static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
 {
     constexpr int BM = WM * 64, BN = WN * 128;
-    constexpr int RING = GNST * (BM + BN) * 64, STAGING = 8 * 32 * 132 * 4;
+    constexpr int RING = GNST * (BM + BN) * 64, STAGING = WM * WN * 32 * 132 * 4;
     constexpr int LDS = (VEC && STAGING > RING) ? STAGING : RING;
     static bool attr_done = false;
     if (!attr_done) {
@@ -270,7 +282,7 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
     q.order = (order_env == 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
     dim3 grid(q.tiles_m, q.tiles_n, batch * p.splitk);
     if (q.order == 1) grid = dim3(((q.tiles_m * q.tiles_n + 7) / 8) * 8, 1, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(512), LDS, stream, q);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(WM * WN * 64), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -301,5 +313,9 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     const int batch = batch1 * batch2;
     if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
     if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);
+    static const int tile_env = getenv("EMDR2_GEMM_TILE") ? atoi(getenv("EMDR2_GEMM_TILE")) : 42;
+    // EMDR2_GEMM_TILE=22: 128 x 256 tiles on 4 waves, two workgroups per CU (one's epilogue overlaps the other's MFMA loop).  Measured
+    // 5-8 % SLOWER than 256 x 256 on the step's linears (1.5x the L2->LDS operand traffic per flop), kept for experiments only.
+    if (tile_env == 22 && split_k == 1) return launch_gemm<2, 2>(p, batch, (hipStream_t)stream);
     return launch_gemm<4, 2>(p, batch, (hipStream_t)stream);
 }
