@@ -34,6 +34,7 @@ struct GemmParams {
     int gelu, out_f32;
     float drop_p;             // dropout on (acc*alpha + bias [gelu]) before the residual add: bias_dropout_add (transformer.py:397-413)
     uint32_t seed;            // keep bit = emdr2_keep(row_hash(seed, m), n, thr)
+    int ablate;               // timing experiments (EMDR2_GEMM_ABLATE): 1 = no epilogue, 2 = no k-loop, 3 = epilogue without global stores
     int tiles_m, tiles_n, order; // order 1: 1-D grid, n-tiles fastest inside a per-XCD contiguous tile range (operand A read once from HBM)
     int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
@@ -45,6 +46,14 @@ __device__ __forceinline__ uint16_t f32_to_bf16(float f)
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); // quiet NaN
     u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
     return (uint16_t)(u >> 16);
+}
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float floatx2_t __attribute__((ext_vector_type(2)));
+// two fp32 -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32, round to nearest even, NaN preserved)
+__device__ __forceinline__ uint32_t pack2_bf16(float a, float b)
+{
+    const floatx2_t v = {a, b};
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
 
@@ -113,6 +122,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     const int c_begin = zs * per;
     const int nch = (c_begin + per <= nch_all ? per : (nch_all > c_begin ? nch_all - c_begin : 0));
     if (nch == 0) return;
+    const int nch_run = p.ablate == 2 ? 0 : nch;
     int pf_c = 0, pf_stage = 0;
     auto issue = [&]() {
         const int c = c_begin + (pf_c < nch ? pf_c : nch - 1);      // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
@@ -138,7 +148,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     issue();
     issue();
     int cs = 0;
-    for (int c = 0; c < nch; ++c) {
+    for (int c = 0; c < nch_run; ++c) {
         if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
@@ -163,6 +173,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two speculative chunks
 
+    if (p.ablate == 1) { if (acc[0][0][0] == 123.456f) ((float *)p.C)[0] = acc[1][3][5]; return; }
     if (VEC) {
         // ---- vector epilogue: acc -> LDS (fp32, wave-private 32 x 128 half tile, pitch 132) -> 8-wide row segments ----------
         __syncthreads();                                           // every wave is done with the operand ring
@@ -172,6 +183,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
         float bv[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) bv[j] = (p.bias && ncol + j < p.N) ? p.bias[ncol + j] : 0.f;
+        const bool affine = p.bias != nullptr || p.alpha != 1.0f;       // plain GEMMs skip the per-element multiply-add
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {
             // residual rows of this half: all eight 16-byte loads go out BEFORE the LDS round trip, so their HBM latency overlaps the
@@ -199,12 +211,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
                 if (m < p.M && ncol < p.N) {
                     const long long o = coff + (long long)m * p.ldc + ncol;
+                    if (affine) {
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bv[j];
+                        for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bv[j];
+                    }
                     if (p.C2) {
                         uint32_t w[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
+                        for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
                         *(uint4 *)((uint16_t *)p.C2 + o) = make_uint4(w[0], w[1], w[2], w[3]);
                     }
                     if (p.gelu) {
@@ -228,8 +242,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     }
                     uint32_t w[4];
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) w[j] = (uint32_t)f32_to_bf16(v[2 * j]) | ((uint32_t)f32_to_bf16(v[2 * j + 1]) << 16);
-                    *(uint4 *)((uint16_t *)p.C + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
+                    if (p.ablate != 3 || w[0] == 0x12345678u) *(uint4 *)((uint16_t *)p.C + o) = make_uint4(w[0], w[1], w[2], w[3]);
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this half are done before the next half overwrites
@@ -279,6 +293,8 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
     GemmParams q = p;
     q.tiles_m = (p.M + BM - 1) / BM; q.tiles_n = (p.N + BN - 1) / BN;
     static const int order_env = getenv("EMDR2_GEMM_ORDER") ? atoi(getenv("EMDR2_GEMM_ORDER")) : 1;
+    static const int ablate_env = getenv("EMDR2_GEMM_ABLATE") ? atoi(getenv("EMDR2_GEMM_ABLATE")) : 0;
+    q.ablate = ablate_env;
     q.order = (order_env == 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
     dim3 grid(q.tiles_m, q.tiles_n, batch * p.splitk);
     if (q.order == 1) grid = dim3(((q.tiles_m * q.tiles_n + 7) / 8) * 8, 1, batch * p.splitk);
