@@ -55,7 +55,18 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b)
     const floatx2_t v = {a, b};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
 }
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// erf-form GELU 0.5 x (1 + erf(x / sqrt 2)) (transformer.py:80,103-104: F.gelu, not the tanh fusion).  erf by Abramowitz-Stegun 7.1.26
+// (|error| <= 1.5e-7, far below the bf16 output grid) on one v_rcp and one v_exp: ~14 VALU ops where the library erff cost ~3x that and
+// made the FFN1 epilogue as long as a third of its k-loop.
+__device__ __forceinline__ float gelu_erf(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
+    const float erf_abs = fmaf(-poly, e, 1.0f);
+    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+}
 
 // VEC: bf16 output staged through LDS per wave and written as 16-byte row segments (bias / GELU / pre-activation / residual
 // applied on 8-element vectors); otherwise (fp32 output, split-K atomics, unaligned leading dimensions) the scalar epilogue.

@@ -252,3 +252,13 @@ def test_weight_gradient_gemm_tn_with_bias_gradient(M, N, Kd):
     ref = dy.float().T @ x.float()
     assert torch.allclose(dW, ref, rtol=2e-3, atol=2e-3 * (M ** 0.5))
     assert torch.allclose(db, dy.float().sum(0), rtol=1e-3, atol=1e-3 * (M ** 0.5))
+
+
+def test_gelu_epilogue_accuracy_vs_exact_erf():
+    """The epilogue's erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) against torch's exact-erf GELU in fp32: identity GEMM passes x through."""
+    x = torch.linspace(-12.0, 12.0, 256 * 256, device="cuda").reshape(256, 256).bfloat16()
+    eye = torch.eye(256, device="cuda").bfloat16()
+    y = _gemm(eye, x.T.contiguous(), gelu=True, out_f32=True)            # C = gelu(I x) in fp32
+    ref = torch.nn.functional.gelu(x.float())
+    err = (y - ref).abs()
+    assert float(err.max()) < 2e-6 and float((err / (ref.abs() + 1e-3)).max()) < 2e-4
