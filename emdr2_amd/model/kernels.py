@@ -266,6 +266,21 @@ def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
+class _AttentionStash(object):
+    """Selective activation recompute: under per-layer checkpointing the whole layer is re-run in the backward, but the fused attention
+    forward is the one piece whose output is small ([b, s, h] + two fp32 statistics per row) next to its cost (it runs three times per
+    layer and step otherwise).  The checkpoint wrapper (transformer._CheckpointedLayer) puts the stash in 'store' mode for the first run
+    of a layer and in 'consume' mode for its re-run; the key ties an entry to that one wrapper call, so other passes through the same
+    module (the no-grad one-context pass) never see it.  Costs ~45 GB of the 288 GB at the benchmark shape, saves one attention forward
+    per layer and step."""
+
+    def __init__(self):
+        self.mode, self.key, self.store, self.enabled = None, None, {}, True
+
+
+ATTN_STASH = _AttentionStash()
+
+
 class AttentionCoreFn(torch.autograd.Function):
     """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).
     Inputs are the projection outputs themselves: self-attention passes `qsrc` = the packed [b, s, 3, np, hn] QKV tensor (kvsrc None),
@@ -276,7 +291,7 @@ class AttentionCoreFn(torch.autograd.Function):
     kept; the backward rebuilds the probabilities from them."""
 
     @staticmethod
-    def forward(ctx, qsrc, kvsrc, ids_q, ids_k, causal, drop_p=0.0, seed=0):
+    def forward(ctx, qsrc, kvsrc, ids_q, ids_k, causal, drop_p=0.0, seed=0, site=0):
         _check_bf16(qsrc, kvsrc)
         if kvsrc is None:
             q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
@@ -286,6 +301,13 @@ class AttentionCoreFn(torch.autograd.Function):
         sk = k.shape[1]
         dev = q.device
         scale = 1.0 / math.sqrt(hn)
+        stash_key = (ATTN_STASH.key, site) if (ATTN_STASH.enabled and ATTN_STASH.mode and site) else None
+        stashed = ATTN_STASH.store.pop(stash_key, None) if (stash_key and ATTN_STASH.mode == 'consume') else None
+        if stashed is not None:                                                           # the layer's re-run: reuse the first run's output
+            ctxo, m, l = stashed
+            ctx.save_for_backward(qsrc, kvsrc, m, l, ids_q, ids_k, ctxo)
+            ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
+            return ctxo
         m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
         ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
@@ -304,6 +326,8 @@ class AttentionCoreFn(torch.autograd.Function):
             gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
         ctx.save_for_backward(qsrc, kvsrc, m, l, ids_q, ids_k, ctxo)
         ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
+        if stash_key and ATTN_STASH.mode == 'store':
+            ATTN_STASH.store[stash_key] = (ctxo, m, l)
         return ctxo
 
     @staticmethod
@@ -332,7 +356,7 @@ class AttentionCoreFn(torch.autograd.Function):
                                                   dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dv.data_ptr(), dk.stride(0),
                                                   dk.stride(1), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(), D.data_ptr(), b,
                                                   heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, _sp()), "attention_bwd")
-            return dqsrc, dkvsrc, None, None, None, None, None
+            return dqsrc, dkvsrc, None, None, None, None, None, None
         # main orientation: S = scale Q K^T (recomputed), dP = dctx V^T, dS = P (dP_eff - D) with P rebuilt from (m, l)
         S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
@@ -359,12 +383,12 @@ class AttentionCoreFn(torch.autograd.Function):
                 alpha=scale)
         dctxT = head_transpose(dctx.view(b, sq, heads, hn), b, sq, heads, hn)
         gemm_nt(St, sq, dctxT, sq, dv, dv.stride(1), sk, hn, sq, b, heads * sk * sq, heads * hn * sq, dv.stride(0), heads, sk * sq, hn * sq, hn)
-        return dqsrc, dkvsrc, None, None, None, None, None
+        return dqsrc, dkvsrc, None, None, None, None, None, None
 
 
-def attention_core(qsrc, kvsrc, ids_q, ids_k, causal=False, drop_p=0.0, seed=0):
+def attention_core(qsrc, kvsrc, ids_q, ids_k, causal=False, drop_p=0.0, seed=0, site=0):
     """qsrc packed [b, s, 3, np, hn] with kvsrc None (self-attention), or qsrc [b, sq, np, hn] + kvsrc packed [b, sk, 2, np, hn]."""
-    return AttentionCoreFn.apply(qsrc, kvsrc, ids_q, ids_k, causal, drop_p, seed)
+    return AttentionCoreFn.apply(qsrc, kvsrc, ids_q, ids_k, causal, drop_p, seed, site)
 
 
 class EmbeddingFn(torch.autograd.Function):

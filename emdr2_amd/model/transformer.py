@@ -101,7 +101,7 @@ class ParallelAttention(torch.nn.Module):
         seed = K.DROPOUT.seed(self._site_attn) if pa else 0
         if self.attention_type == "self":
             mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(b, sq, 3, self.heads, self.hn)
-            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
+            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(b, sq, h)
         else:
             sk = encoder_output.shape[1]
             if self.kv_cache is not None and self.kv_cache[0] is encoder_output:
@@ -111,7 +111,7 @@ class ParallelAttention(torch.nn.Module):
                 if self.kv_cache is not None:
                     self.kv_cache = (encoder_output, kv)
             q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
-            ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed).view(b, sq, h)
+            ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(b, sq, h)
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
 
@@ -136,6 +136,22 @@ class ParallelTransformerLayer(torch.nn.Module):
         return self.mlp(ln, residual=x)
 
 
+class _CheckpointedLayer(object):
+    """The callable handed to torch.utils.checkpoint for ONE layer invocation: its first call is the forward proper, its second the
+    re-run inside the backward.  It switches the attention stash (kernels.ATTN_STASH) between storing and consuming accordingly."""
+
+    def __init__(self, layer):
+        self.layer, self.calls = layer, 0
+
+    def __call__(self, *args):
+        self.calls += 1
+        K.ATTN_STASH.mode, K.ATTN_STASH.key = ('store' if self.calls == 1 else 'consume'), id(self)
+        try:
+            return self.layer(*args)
+        finally:
+            K.ATTN_STASH.mode = K.ATTN_STASH.key = None
+
+
 class ParallelTransformer(torch.nn.Module):
     def __init__(self, cfg, layer_type="encoder", checkpoint_activations=False):
         super().__init__()
@@ -147,7 +163,7 @@ class ParallelTransformer(torch.nn.Module):
     def forward(self, x, ids, causal=False, encoder_output=None, enc_ids=None):
         for layer in self.layers:
             if self.checkpoint_activations and torch.is_grad_enabled():
-                x = torch.utils.checkpoint.checkpoint(layer, x, ids, causal, encoder_output, enc_ids, use_reentrant=False)
+                x = torch.utils.checkpoint.checkpoint(_CheckpointedLayer(layer), x, ids, causal, encoder_output, enc_ids, use_reentrant=False)
             else:
                 x = layer(x, ids, causal, encoder_output, enc_ids)
         return self.final_layernorm(x)

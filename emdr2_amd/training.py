@@ -55,6 +55,8 @@ class FusedAdam(object):
         for g in self.groups:
             for p in g["params"]:
                 p.grad = None
+        from emdr2_amd.model import kernels
+        kernels.ATTN_STASH.store.clear()      # entries of a forward whose backward never ran must not outlive the step
 
     def state_dict(self):
         """Moments in parameter order (torch-optimizer style: {'step', 'state': {index: {'exp_avg', 'exp_avg_sq'}}})."""

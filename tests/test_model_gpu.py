@@ -196,3 +196,36 @@ def test_dropout_is_reproduced_by_activation_recompute_and_changes_per_step():
     assert not torch.equal(t2.float(), outs[1])
     # the expected value is preserved: train-mode logits scatter around the eval-mode ones
     assert _rel(t2.float(), e1.float()) < 1.0
+
+
+def test_attention_stash_under_checkpointing_gives_identical_gradients():
+    """Selective recompute: reusing the first run's attention output in the layer re-run must not change anything, must leave no stash
+    behind, and must not leak into a no-grad pass through the same modules between forward and backward."""
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.model.transformer import Config, T5Model
+    rng = np.random.default_rng(4)
+    enc_ids, dec_ids = _ids(rng, (8, 64), 512).cuda(), _ids(rng, (8, 32), 512).cuda()
+    grads = []
+    for enabled in (False, True):
+        torch.manual_seed(0)
+        K.DROPOUT._sites = 0
+        cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05,
+                     hidden_dropout=0.1, attention_dropout=0.1)
+        m = T5Model(cfg, 512, checkpoint_activations=True)
+        m.train()
+        K.DROPOUT.step = 3
+        K.ATTN_STASH.enabled = enabled
+        K.ATTN_STASH.store.clear()
+        try:
+            logits, _ = m(enc_ids, dec_ids)
+            if enabled:
+                assert len(K.ATTN_STASH.store) == 6                      # 2 encoder + 2 x 2 decoder attentions
+            with torch.no_grad():
+                m(enc_ids.flip(0), dec_ids)                              # another pass through the same modules before the backward
+            logits.float().square().mean().backward()
+            assert len(K.ATTN_STASH.store) == 0
+        finally:
+            K.ATTN_STASH.enabled = True
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    for k in grads[0]:
+        assert _rel(grads[1][k], grads[0][k]) < 1e-3, k
