@@ -97,6 +97,52 @@ __global__ void __launch_bounds__(256) layernorm_fwd_kernel(const uint16_t *x, c
     }
 }
 
+// H == 768 (every LayerNorm of the base configuration): half a wave per row, the row's 96 16-byte granules held in registers (3 per
+// lane, all lanes busy, one HBM read), reductions over 32 lanes, gamma / beta fetched once per lane for both rows of the wave.
+__global__ void __launch_bounds__(256) layernorm_fwd768_kernel(const uint16_t *x, const float *gamma, const float *beta, uint16_t *y, float *mean,
+                                                               float *rstd, long long rows, float eps)
+{
+    const int lane = threadIdx.x & 63, l31 = lane & 31;
+    const long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * 2 + (lane >> 5);
+    const bool live = row < rows;
+    const uint16_t *xr = x + (live ? row : rows - 1) * 768;
+    uint4 v[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) v[i] = *(const uint4 *)(xr + (i * 32 + l31) * 8);
+    float f[3][8], s = 0.f, ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const uint32_t w[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            f[i][2 * j] = bf2f((uint16_t)(w[j] & 0xffff)); f[i][2 * j + 1] = bf2f((uint16_t)(w[j] >> 16));
+            s += f[i][2 * j] + f[i][2 * j + 1];
+            ss += f[i][2 * j] * f[i][2 * j] + f[i][2 * j + 1] * f[i][2 * j + 1];
+        }
+    }
+#pragma unroll
+    for (int o = 16; o >= 1; o >>= 1) { s += __shfl_xor(s, o); ss += __shfl_xor(ss, o); }   // within the 32 lanes of the row
+    const float mu = s * (1.0f / 768.0f);
+    const float var = fmaxf(ss * (1.0f / 768.0f) - mu * mu, 0.f);
+    const float rs = rsqrtf(var + eps);
+    if (live && l31 == 0) { mean[row] = mu; rstd[row] = rs; }
+    if (!live) return;
+    uint16_t *yr = y + row * 768;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = (i * 32 + l31) * 8;
+        const float4 g0 = *(const float4 *)(gamma + c), g1 = *(const float4 *)(gamma + c + 4);
+        const float4 b0 = *(const float4 *)(beta + c), b1 = *(const float4 *)(beta + c + 4);
+        const float gm[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w}, bt[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            o[j] = (uint32_t)f2bf(fmaf((f[i][2 * j] - mu) * rs, gm[2 * j], bt[2 * j])) |
+                   ((uint32_t)f2bf(fmaf((f[i][2 * j + 1] - mu) * rs, gm[2 * j + 1], bt[2 * j + 1])) << 16);
+        *(uint4 *)(yr + c) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+}
+
 // dx = rstd * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*gamma ; optional residual-branch gradient added on the way out.
 // Block = 32 rows: phase 1 one wave per row computes the two row means into LDS; phase 2 every thread owns columns tid, tid+256, ...
 // for all 32 rows (dgamma / dbeta partials stay in registers; one global atomicAdd per column per block).
@@ -138,6 +184,82 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t *dy, 
         }
         atomicAdd(&dgamma[c], ag);
         atomicAdd(&dbeta[c], ab);
+    }
+}
+
+// H == 768 backward: half a wave per row with dy and x in registers (one HBM read each), persistent waves accumulate the dgamma / dbeta
+// partials of their 24 columns per lane in registers across all their rows; one LDS reduction and one atomicAdd per column per workgroup.
+__global__ void __launch_bounds__(256) layernorm_bwd768_kernel(const uint16_t *dy, const uint16_t *x, const float *gamma, const float *mean,
+                                                               const float *rstd, const uint16_t *dres, uint16_t *dx, float *dgamma, float *dbeta,
+                                                               long long rows)
+{
+    __shared__ float red[2][4][768];
+    const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
+    float gm[3][8], ag[3][8], ab[3][8];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = (i * 32 + l31) * 8;
+        const float4 g0 = *(const float4 *)(gamma + c), g1 = *(const float4 *)(gamma + c + 4);
+        gm[i][0] = g0.x; gm[i][1] = g0.y; gm[i][2] = g0.z; gm[i][3] = g0.w; gm[i][4] = g1.x; gm[i][5] = g1.y; gm[i][6] = g1.z; gm[i][7] = g1.w;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { ag[i][j] = 0.f; ab[i][j] = 0.f; }
+    }
+    const long long npairs = (rows + 1) >> 1, stride = (long long)gridDim.x * 4;
+    for (long long rp = (long long)blockIdx.x * 4 + wave; rp < npairs; rp += stride) {
+        const long long row = rp * 2 + half;
+        if (row >= rows) continue;                                       // only the odd tail row's partner half-wave
+        const uint16_t *xr = x + row * 768, *dr = dy + row * 768;
+        uint4 xv[3], dv[3], rv[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) { xv[i] = *(const uint4 *)(xr + (i * 32 + l31) * 8); dv[i] = *(const uint4 *)(dr + (i * 32 + l31) * 8); }
+        if (dres) {
+#pragma unroll
+            for (int i = 0; i < 3; ++i) rv[i] = *(const uint4 *)(dres + row * 768 + (i * 32 + l31) * 8);
+        }
+        const float mu = mean[row], rs = rstd[row];
+        float xh[3][8], g[3][8], s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t xw[4] = {xv[i].x, xv[i].y, xv[i].z, xv[i].w}, dw[4] = {dv[i].x, dv[i].y, dv[i].z, dv[i].w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const float xe = bf2f((uint16_t)((j & 1) ? xw[j >> 1] >> 16 : xw[j >> 1] & 0xffff));
+                const float de = bf2f((uint16_t)((j & 1) ? dw[j >> 1] >> 16 : dw[j >> 1] & 0xffff));
+                xh[i][j] = (xe - mu) * rs;
+                g[i][j] = de * gm[i][j];
+                s1 += g[i][j]; s2 += g[i][j] * xh[i][j];
+                ag[i][j] += de * xh[i][j]; ab[i][j] += de;
+            }
+        }
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        const float m1 = s1 * (1.0f / 768.0f), m2 = s2 * (1.0f / 768.0f);
+        uint16_t *xo = dx + row * 768;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const uint32_t rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
+            uint32_t o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float a = rs * (g[i][2 * j] - m1 - xh[i][2 * j] * m2), b = rs * (g[i][2 * j + 1] - m1 - xh[i][2 * j + 1] * m2);
+                if (dres) { a += bf2f((uint16_t)(rw[j] & 0xffff)); b += bf2f((uint16_t)(rw[j] >> 16)); }
+                o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+            }
+            *(uint4 *)(xo + (i * 32 + l31) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+    }
+    // both half-waves own the same columns: fold, then reduce the 4 waves through LDS
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float a = ag[i][j] + __shfl_xor(ag[i][j], 32), b = ab[i][j] + __shfl_xor(ab[i][j], 32);
+            if (half == 0) { red[0][wave][(i * 32 + l31) * 8 + j] = a; red[1][wave][(i * 32 + l31) * 8 + j] = b; }
+        }
+    __syncthreads();
+    for (int c = threadIdx.x; c < 768; c += 256) {
+        atomicAdd(&dgamma[c], red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+        atomicAdd(&dbeta[c], red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
     }
 }
 
@@ -527,6 +649,11 @@ extern "C" int emdr2_layernorm_fwd(const void *x, const float *gamma, const floa
                                    int H, float eps, void *stream)
 {
     if (!x || !gamma || !beta || !y || !mean || !rstd || rows < 1 || H < 8 || (H & 7)) return -1;
+    if (H == 768 && !((uintptr_t)x & 15) && !((uintptr_t)y & 15) && !((uintptr_t)gamma & 15) && !((uintptr_t)beta & 15)) {
+        hipLaunchKernelGGL(layernorm_fwd768_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, gamma,
+                           beta, (uint16_t *)y, mean, rstd, (long long)rows, eps);
+        return LAUNCH_OK();
+    }
     hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)x, gamma, beta,
                        (uint16_t *)y, mean, rstd, (long long)rows, H, eps);
     return LAUNCH_OK();
@@ -536,6 +663,14 @@ extern "C" int emdr2_layernorm_bwd(const void *dy, const void *x, const float *g
                                    void *dx, float *dgamma, float *dbeta, int64_t rows, int H, void *stream)
 {
     if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || rows < 1 || H < 1 || H > 8192) return -1;
+    const bool al = !(((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)gamma) & 15);
+    if (H == 768 && al) {
+        long long blocks = (rows + 7) / 8;
+        if (blocks > 2048) blocks = 2048;                               // persistent: each wave walks ~100 row pairs at the reader's shape
+        hipLaunchKernelGGL(layernorm_bwd768_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy,
+                           (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta, (long long)rows);
+        return LAUNCH_OK();
+    }
     const int rpb = LN_ROWS;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)dy, (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta,

@@ -262,3 +262,23 @@ def test_gelu_epilogue_accuracy_vs_exact_erf():
     ref = torch.nn.functional.gelu(x.float())
     err = (y - ref).abs()
     assert float(err.max()) < 2e-6 and float((err / (ref.abs() + 1e-3)).max()) < 2e-4
+
+
+@pytest.mark.parametrize("rows,H", [(1000, 768), (7, 768), (4096, 128), (513, 1024), (33, 3072)])
+def test_layernorm_forward_backward_vs_torch(rows, H):
+    """Generic kernel and the H = 768 half-wave-per-row fast path, odd row counts included."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(rows + H)
+    x = (torch.randn((rows, H), generator=g, device="cuda") * 2 + 0.5).bfloat16().requires_grad_(True)
+    gamma = torch.nn.Parameter(torch.randn(H, generator=g, device="cuda"))
+    beta = torch.nn.Parameter(torch.randn(H, generator=g, device="cuda"))
+    y = K.layer_norm(x, gamma, beta, 1e-5)
+    w = torch.randn(y.shape, generator=g, device="cuda")
+    (y.float() * w).sum().backward()
+    xf = x.detach().float().requires_grad_(True)
+    gf, bf = gamma.detach().clone().requires_grad_(True), beta.detach().clone().requires_grad_(True)
+    ref = torch.nn.functional.layer_norm(xf, (H,), gf, bf, 1e-5)
+    (ref * w).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert rel(y, ref) < 1e-2
+    assert rel(x.grad, xf.grad) < 2e-2 and rel(gamma.grad, gf.grad) < 2e-2 and rel(beta.grad, bf.grad) < 2e-2
