@@ -58,6 +58,14 @@ __device__ __forceinline__ uint32_t pack2_bf16(float a, float b)
 // erf-form GELU 0.5 x (1 + erf(x / sqrt 2)) (transformer.py:80,103-104: F.gelu, not the tanh fusion).  erf by Abramowitz-Stegun 7.1.26
 // (|error| <= 1.5e-7, far below the bf16 output grid) on one v_rcp and one v_exp: ~14 VALU ops where the library erff cost ~3x that and
 // made the FFN1 epilogue as long as a third of its k-loop.
+// outputs are written once and not re-read by this kernel: streaming stores keep them from evicting the A panels the other n-tiles of
+// the XCD are about to reuse (EMDR2_GEMM_NT=0 switches back to plain stores for A/B runs)
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store_stream(uint16_t *dst, uint4 v)
+{
+    const u32x4_t x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, (u32x4_t *)dst);
+}
 __device__ __forceinline__ float gelu_erf(float x)
 {
     const float z = fabsf(x) * 0.70710678118654752f;
@@ -205,7 +213,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                 for (int g = 0; g < 8; ++g) {
                     const int m = m0 + wm * 64 + mi * 32 + g * 4 + rsub;
                     rr[g] = make_uint4(0, 0, 0, 0);
-                    if (m < p.M && ncol < p.N) rr[g] = *(const uint4 *)((const uint16_t *)p.R + coff + (long long)m * p.ldc + ncol);
+                    if (m < p.M && ncol < p.N) {
+                        const u32x4_t t = __builtin_nontemporal_load((const u32x4_t *)((const uint16_t *)p.R + coff + (long long)m * p.ldc + ncol));
+                        rr[g] = make_uint4(t.x, t.y, t.z, t.w);
+                    }
                 }
             }
 #pragma unroll
@@ -230,7 +241,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                         uint32_t w[4];
 #pragma unroll
                         for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
-                        *(uint4 *)((uint16_t *)p.C2 + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                        store_stream((uint16_t *)p.C2 + o, make_uint4(w[0], w[1], w[2], w[3]));
                     }
                     if (p.gelu) {
 #pragma unroll
@@ -254,7 +265,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     uint32_t w[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
-                    if (p.ablate != 3 || w[0] == 0x12345678u) *(uint4 *)((uint16_t *)p.C + o) = make_uint4(w[0], w[1], w[2], w[3]);
+                    if (p.ablate != 3 || w[0] == 0x12345678u) store_stream((uint16_t *)p.C + o, make_uint4(w[0], w[1], w[2], w[3]));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this half are done before the next half overwrites

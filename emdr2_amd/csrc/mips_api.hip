@@ -165,7 +165,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         sp.n_q = nqp;
         sp.capq = CAPQ;
         sp.dense_row0 = 0;
-        sp.tune = env_int("EMDR2_MIPS_TUNE", 1);
+        sp.tune = env_int("EMDR2_MIPS_TUNE", 17);
         sp.trace = (unsigned long long *)w.cand + (size_t)511 * CAPQ; // scratch tail of the candidate area (ABL 9 only)
 
         int64_t done = 0, seg_end = dense_rows;

@@ -19,7 +19,7 @@ struct ScanParams {
     int n_q;
     unsigned capq;
     int dense_row0;       // MODE 1: first row of the dense segment
-    int tune;             // experiment bits (EMDR2_MIPS_TUNE): 1 = prio on MFMA phase, 2 = prio on load phase, 4 = DMA before reads
+    int tune;             // bits (EMDR2_MIPS_TUNE, default 17): 1 = prio on MFMA phase, 2 = prio on load phase, 4 = DMA before reads, 16 = non-temporal index-row loads (+5 % in the HBM-bound regime)
     unsigned long long *trace; // ABL 9: s_memtime stamps [16 chunks][8 waves][10 points]
 };
 

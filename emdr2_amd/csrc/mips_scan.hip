@@ -25,6 +25,11 @@ __device__ __forceinline__ void glds16(const char *src, char *lds_dst)
 {
     __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)lds_dst, 16, 0, 0);
 }
+// same with the non-temporal cache policy (aux bit 1 = nt): for the index rows, which are read exactly once per search
+__device__ __forceinline__ void glds16_nt(const char *src, char *lds_dst)
+{
+    __builtin_amdgcn_global_load_lds((gptr_t *)src, (lptr_t *)lds_dst, 16, 0, 2);
+}
 
 // MODE 0: threshold filter -> survivor queue -> candidate buffers (the production path)
 // MODE 1: dense: every (row, query) score is written to cand[q][row - row0] (first segment)
@@ -82,7 +87,10 @@ __global__ void __launch_bounds__(512) mips_scan_kernel(ScanParams p)
         for (int j = 0; j < E_PW; ++j) {
             const int pe = wave + 8 * j;
             const size_t stripe = (size_t)t * STRIPES_PER_TILE + (pe >> 3);
-            if (ABL != 3) glds16(p.e_tiled + (stripe * nch + pf_c) * STRIPE_CHUNK_BYTES + (pe & 7) * 1024 + lane * 16, sb + pe * 1024);
+            if (ABL != 3) {
+                const char *src = p.e_tiled + (stripe * nch + pf_c) * STRIPE_CHUNK_BYTES + (pe & 7) * 1024 + lane * 16;
+                if (p.tune & 16) glds16_nt(src, sb + pe * 1024); else glds16(src, sb + pe * 1024);
+            }
         }
 #pragma unroll
         for (int j = 0; j < Q_PW; ++j) {
