@@ -55,3 +55,13 @@ def test_mmap_dataset_reads_reference_files_and_round_trips(tmp_path):
         open(str(tmp_path / "bad.idx"), "wb").write(b"nonsense-nonsense-nonsense")
         open(str(tmp_path / "bad.bin"), "wb").write(b"")
         MMapIndexedDataset(str(tmp_path / "bad"))
+
+
+def test_answer_presence_validation_matches_the_reference():
+    from emdr2_amd.tasks.openqa.dense_retriever.evaluation.qa_validation import calculate_matches, has_answer
+    ref = json.load(open(os.path.join(GOLD, "retrieval_ref.json")))
+    for answers, text, match, expect in ref["cases"]:
+        assert has_answer(answers, text, match) == expect, (answers, text, match)
+    docs = {int(k): tuple(v) for k, v in ref["docs"].items()}
+    stats = calculate_matches(docs, [q[0] for q in ref["questions"]], [(q[1], q[2]) for q in ref["questions"]], match_type="string")
+    assert list(stats.top_k_hits) == ref["top_k_hits"] and [list(h) for h in stats.questions_doc_hits] == ref["questions_doc_hits"]

@@ -119,3 +119,54 @@ def test_checkpoint_layout_matches_the_reference_model(tmp_path):
         assert torch.equal(p, q), k
     checkpointing.load_dualencoder_checkpoint(other.retriever_model, str(tmp_path), key_list=["retriever/biencoder_model"])
     checkpointing.load_t5_state_dict(other.language_model, nested["encoder/t5_model"])
+
+
+def test_retrieval_evaluator_reports_topk_accuracy_on_a_planted_corpus(tmp_path):
+    """f3: questions -> token ids -> query tower -> FaissMIPSIndex (fp32 scores) -> answer-string validation -> top-k accuracy.  Planted
+    geometry: a stub tower embeds a sequence by its first word, every passage is indexed under its first word, and each question repeats
+    its passage -- so the passage is retrieved among the (few) passages sharing that first word and top-5 accuracy must be exactly 1.
+    The real BERT tower is run through the same evaluator afterwards (plumbing check: shapes, eval mode, monotone accuracies)."""
+    from emdr2_amd.data.emdr2_index import OpenRetreivalDataStore
+    from emdr2_amd.model.transformer import Config, PretrainedBertModel
+    from emdr2_amd.tasks.openqa.dense_retriever.evaluation.evaluate import OpenRetrievalEvaluator, read_evidence_text
+    from emdr2_amd.tokenizer import BertWordPieceTokenizer
+    tmp = str(tmp_path)
+    vocab, ev, emb = _make_world(tmp, n_docs=200)
+    t = BertWordPieceTokenizer(vocab)
+    docs = read_evidence_text(ev)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    table = torch.randn((t.vocab_size, 128), generator=g, device="cuda").half()
+
+    class FirstWordTower(torch.nn.Module):
+        def forward(self, ids, types):
+            return table[ids[:, 1]]
+
+    store = OpenRetreivalDataStore(os.path.join(tmp, "planted.pkl"), load_from_path=False, rank=0)
+    first = [t.tokenize(docs[d][0])[0] for d in range(1, 201)]
+    store.add_block_data(list(range(1, 201)), table[torch.tensor(first, device="cuda")].cpu().numpy())
+    qa = os.path.join(tmp, "retr.tsv")
+    with open(qa, "w") as f:
+        for d in range(1, 41):
+            words = docs[d][0].split()
+            f.write("%s\t%s\n" % (docs[d][0], json.dumps([" ".join(words[3:9])])))
+    evaluator = OpenRetrievalEvaluator(FirstWordTower(), t, store, docs, hidden_size=128, seq_length_ret=64, batch_size=16, topk_retrievals=20,
+                                       report_topk_accuracies=(1, 5, 20))
+    acc, stats = evaluator.evaluate(qa)
+    same_first = max(first.count(w) for w in set(first))
+    assert same_first <= 20
+    assert set(acc) == {1, 5, 20} and acc[1] <= acc[5] <= acc[20] == 1.0
+    for qi, d in enumerate(range(1, 41)):                                # the passage itself is in the list, at a position below the tie group size
+        ids = evaluator.mips_index.search_mips_index(table[first[d - 1]][None], top_k=20, reconstruct=False)[1][0].tolist()
+        assert d in ids[:first.count(first[d - 1])]
+    # the real tower through the same evaluator
+    torch.manual_seed(1)
+    cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=64, init_method_std=0.2,
+                 hidden_dropout=0.1, attention_dropout=0.1)
+    tower = PretrainedBertModel(cfg, 384).train()
+    store2 = OpenRetreivalDataStore(os.path.join(tmp, "planted2.pkl"), load_from_path=False, rank=0)
+    store2.add_block_data(list(range(1, 201)), table[torch.tensor(first, device="cuda")].cpu().numpy())
+    ev2 = OpenRetrievalEvaluator(tower, t, store2, docs, hidden_size=128, seq_length_ret=64, batch_size=16, topk_retrievals=20, report_topk_accuracies=(1, 20))
+    q1, q2 = ev2.generate_query_vectors([docs[1][0], docs[2][0]]), ev2.generate_query_vectors([docs[1][0], docs[2][0]])
+    assert q1.shape == (2, 128) and torch.equal(q1, q2) and tower.training      # eval mode inside (no dropout), training mode restored
+    acc2, _ = ev2.evaluate(qa)
+    assert 0.0 <= acc2[1] <= acc2[20] <= 1.0
