@@ -121,3 +121,42 @@ def test_shard_bounds_follow_torch_chunk():
             ref = [c.numel() for c in torch.chunk(torch.empty(n), w)] if n else []
             assert sizes[:len(ref)] == ref and sum(sizes) == n and all(s == 0 for s in sizes[len(ref):])
             assert all(b[i][1] == b[i + 1][0] for i in range(w - 1))
+
+
+# ---- evidence indexing across ranks (a17, the reference's data-store flow) ---------------------------------------------------------
+def _indexer_worker(rank, world, port, n_docs, batch, path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emdr2_amd.indexer_emdr2 import IndexBuilder
+
+    class _Arena(object):
+        pass
+    arena = _Arena(); arena.n_docs = n_docs
+
+    class _Builder(IndexBuilder):
+        def embed(self, doc_ids):                                        # the GPU tower is out of scope here: rows are a function of the id
+            ids = torch.as_tensor(np.asarray(doc_ids), dtype=torch.float32)
+            return (ids[:, None] * torch.tensor([1.0, 0.5, -0.25, 2.0])[None, :]).to(torch.float16)
+
+    b = _Builder(None, arena, 32, 101, 102, 0, batch_size=batch, log_interval=1 << 30)
+    assert (b.is_main_builder, b.num_total_builders) == (rank == 0, world)
+    b.build_and_save_index(path)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_index_builder_splits_batches_like_the_reference_sampler_and_merges_shards(tmp_path):
+    """world_size 2: every global batch of batch_size * world passages is cut into contiguous per-rank slices (DistributedBatchSampler,
+    data/samplers.py:142-148), each rank writes its shard file, rank 0 merges; every passage appears exactly once with its own row."""
+    from emdr2_amd.data.emdr2_index import OpenRetreivalDataStore
+    n_docs, batch, world = 103, 8, 2
+    path = str(tmp_path / "emb.pkl")
+    mp.spawn(_indexer_worker, args=(world, _free_port(), n_docs, batch, path), nprocs=world, join=True)
+    store = OpenRetreivalDataStore(path, load_from_path=True)
+    assert sorted(store.embed_data) == list(range(1, n_docs + 1))
+    for d, row in store.embed_data.items():
+        assert row.dtype == np.float16 and np.array_equal(row, (np.float32(d) * np.array([1.0, 0.5, -0.25, 2.0], dtype=np.float32)).astype(np.float16))
+    keys = list(store.embed_data)                                        # rank 0's rows first (its own shard), then rank 1's
+    assert keys[:8] == list(range(1, 9)) and keys[8:16] == list(range(17, 25))
+    assert not os.path.isdir(os.path.splitext(path)[0] + "_tmp")
