@@ -156,7 +156,8 @@ def main():
                                    % (B, K, S_ret, S, L, args.rows, args.layers),
                        "global_batch": B * world, "params": n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
                        "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss),
-                       "reindex_rows_per_step": args.reindex_rows_per_step},
+                       "reindex_rows_per_step": args.reindex_rows_per_step,
+                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
                          "traffic": None, "flops_per_step_per_gpu": fl, "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"},
         }), flush=True)

@@ -293,6 +293,9 @@ class AttentionCoreFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qsrc, kvsrc, ids_q, ids_k, causal, drop_p=0.0, seed=0, site=0):
         _check_bf16(qsrc, kvsrc)
+        for ids in (ids_q, ids_k):
+            if ids.dtype != torch.int64 or not ids.is_contiguous() or not ids.is_cuda:
+                raise TypeError("token ids must be contiguous CUDA int64 tensors (the kernels derive the masks from them)")
         if kvsrc is None:
             q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
         else:
