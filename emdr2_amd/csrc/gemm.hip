@@ -78,10 +78,10 @@ __device__ __forceinline__ float gelu_erf(float x)
 
 // VEC: bf16 output staged through LDS per wave and written as 16-byte row segments (bias / GELU / pre-activation / residual
 // applied on 8-element vectors); otherwise (fp32 output, split-K atomics, unaligned leading dimensions) the scalar epilogue.
-template <int WM, int WN, bool VEC>
+template <int WM, int WN, bool VEC, int MI = 2>
 __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
 {
-    constexpr int BM = WM * 64, BN = WN * 128;
+    constexpr int BM = WM * 32 * MI, BN = WN * 128;                   // a wave owns (32 MI) x 128 outputs: MI = 2 -> 64 x 128, MI = 4 -> 128 x 128
     constexpr int A_STAGE = BM * 64, B_STAGE = BN * 64, STAGE = A_STAGE + B_STAGE;
     constexpr int NW = WM * WN;                                       // waves per workgroup: each owns a 64 x 128 output sub-tile
     constexpr int A_PW = BM / (16 * NW), B_PW = BN / (16 * NW), PPW = A_PW + B_PW;   // 1-KiB DMA pieces per wave and stage
@@ -115,7 +115,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
         const int sp = ((ks * 2 + hi) ^ swz) << 4;
-        a_off[ks] = (wm * 64 + l31) * 64 + sp;
+        a_off[ks] = (wm * 32 * MI + l31) * 64 + sp;
         b_off[ks] = A_STAGE + (wn * 128 + l31) * 64 + sp;
     }
 
@@ -156,9 +156,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
         pf_stage = (pf_stage == GNST - 1) ? 0 : pf_stage + 1;
     };
 
-    floatx16 acc[2][4];
+    floatx16 acc[MI][4];
 #pragma unroll
-    for (int mi = 0; mi < 2; ++mi)
+    for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     issue();
     int cs = 0;
     for (int c = 0; c < nch_run; ++c) {
-        if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        if (PPW == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (PPW == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         else if (PPW == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -178,13 +179,13 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
         cs = (cs == GNST - 1) ? 0 : cs + 1;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            bf16x8 a[2], b[4];
+            bf16x8 a[MI], b[4];
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi) a[mi] = *(const bf16x8 *)(sb + a_off[ks] + mi * 2048);
+            for (int mi = 0; mi < MI; ++mi) a[mi] = *(const bf16x8 *)(sb + a_off[ks] + mi * 2048);
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) b[ni] = *(const bf16x8 *)(sb + b_off[ks] + ni * 2048);
 #pragma unroll
-            for (int mi = 0; mi < 2; ++mi)
+            for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni)
                     acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mi], b[ni], acc[mi][ni], 0, 0, 0);
@@ -204,14 +205,14 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
         for (int j = 0; j < 8; ++j) bv[j] = (p.bias && ncol + j < p.N) ? p.bias[ncol + j] : 0.f;
         const bool affine = p.bias != nullptr || p.alpha != 1.0f;       // plain GEMMs skip the per-element multiply-add
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
             // residual rows of this half: all eight 16-byte loads go out BEFORE the LDS round trip, so their HBM latency overlaps the
             // staging instead of serialising one load per 4-row step (that chain cost more than the whole k-loop at K = 768)
             uint4 rr[8];
             if (p.R) {
 #pragma unroll
                 for (int g = 0; g < 8; ++g) {
-                    const int m = m0 + wm * 64 + mi * 32 + g * 4 + rsub;
+                    const int m = m0 + wm * 32 * MI + mi * 32 + g * 4 + rsub;
                     rr[g] = make_uint4(0, 0, 0, 0);
                     if (m < p.M && ncol < p.N) {
                         const u32x4_t t = __builtin_nontemporal_load((const u32x4_t *)((const uint16_t *)p.R + coff + (long long)m * p.ldc + ncol));
@@ -228,7 +229,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
 #pragma unroll
             for (int g = 0; g < 8; ++g) {
                 const int rl = g * 4 + rsub;
-                const int m = m0 + wm * 64 + mi * 32 + rl;
+                const int m = m0 + wm * 32 * MI + mi * 32 + rl;
                 const float4 lo = *(const float4 *)(wl + rl * 132 + seg * 8), hi4 = *(const float4 *)(wl + rl * 132 + seg * 8 + 4);
                 float v[8] = {lo.x, lo.y, lo.z, lo.w, hi4.x, hi4.y, hi4.z, hi4.w};
                 if (m < p.M && ncol < p.N) {
@@ -274,7 +275,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     }
 
     // epilogue.  C layout of the 32x32 MFMA: column n = lane&31, row m = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    const int mrow0 = m0 + wm * 64 + 4 * hi;
+    const int mrow0 = m0 + wm * 32 * MI + 4 * hi;
     const int ncol0 = n0 + wn * 128 + l31;
 #pragma unroll
     for (int ni = 0; ni < 4; ++ni) {
@@ -282,7 +283,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
         if (n >= p.N) continue;
         const float bias = p.bias ? p.bias[n] : 0.f;
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
+        for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = mrow0 + mi * 32 + (r & 3) + 8 * (r >> 2);
@@ -301,15 +302,15 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     }
 }
 
-template <int WM, int WN, bool VEC>
+template <int WM, int WN, bool VEC, int MI = 2>
 static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
 {
-    constexpr int BM = WM * 64, BN = WN * 128;
+    constexpr int BM = WM * 32 * MI, BN = WN * 128;
     constexpr int RING = GNST * (BM + BN) * 64, STAGING = WM * WN * 32 * 132 * 4;
     constexpr int LDS = (VEC && STAGING > RING) ? STAGING : RING;
     static bool attr_done = false;
     if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN, VEC>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        if (hipFuncSetAttribute((const void *)gemm_nt_kernel<WM, WN, VEC, MI>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
         attr_done = true;
     }
     GemmParams q = p;
@@ -320,16 +321,16 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
     q.order = (order_env == 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
     dim3 grid(q.tiles_m, q.tiles_n, batch * p.splitk);
     if (q.order == 1) grid = dim3(((q.tiles_m * q.tiles_n + 7) / 8) * 8, 1, batch * p.splitk);
-    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC>), grid, dim3(WM * WN * 64), LDS, stream, q);
+    hipLaunchKernelGGL((gemm_nt_kernel<WM, WN, VEC, MI>), grid, dim3(WM * WN * 64), LDS, stream, q);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
-template <int WM, int WN>
+template <int WM, int WN, int MI = 2>
 static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
 {
     const bool vec = !p.out_f32 && p.splitk == 1 && !(p.ldc & 7) && !(p.N & 7) && !(p.sC1 & 7) && !(p.sC2 & 7) && !((uintptr_t)p.C & 15) &&
                      !((uintptr_t)p.C2 & 15) && !((uintptr_t)p.R & 15);
-    return vec ? launch_gemm_v<WM, WN, true>(p, batch, stream) : launch_gemm_v<WM, WN, false>(p, batch, stream);
+    return vec ? launch_gemm_v<WM, WN, true, MI>(p, batch, stream) : launch_gemm_v<WM, WN, false, MI>(p, batch, stream);
 }
 
 extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
@@ -355,5 +356,8 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     // EMDR2_GEMM_TILE=22: 128 x 256 tiles on 4 waves, two workgroups per CU (one's epilogue overlaps the other's MFMA loop).  Measured
     // 5-8 % SLOWER than 256 x 256 on the step's linears (1.5x the L2->LDS operand traffic per flop), kept for experiments only.
     if (tile_env == 22 && split_k == 1) return launch_gemm<2, 2>(p, batch, (hipStream_t)stream);
+    // EMDR2_GEMM_TILE=44: 256 x 256 tile on FOUR waves of 128 x 128 (256 accumulator registers per lane, one wave per SIMD): 8 fragment
+    // reads per 16 MFMAs instead of 6 per 8 -> a third less LDS read traffic per flop
+    if (tile_env == 44 && split_k == 1) return launch_gemm<2, 2, 4>(p, batch, (hipStream_t)stream);
     return launch_gemm<4, 2>(p, batch, (hipStream_t)stream);
 }
