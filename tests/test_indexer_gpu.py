@@ -75,7 +75,8 @@ def test_side_stream_refresher_uses_the_snapshot_and_swaps_at_a_step_boundary():
     K.WEIGHTS.invalidate()
     swapped = []
     for it in range(1, 8):
-        indexer.pump()
+        if indexer.pump():
+            indexer.stream.synchronize()                                 # deterministic test: the pass has really finished, not just been queued
         _ = model(torch.randint(1, 2000, (4, S_RET), device="cuda"), torch.zeros((4, S_RET), dtype=torch.int64, device="cuda"))   # main-stream work
         if indexer.maybe_swap(it):
             swapped.append(it)
