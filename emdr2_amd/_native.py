@@ -46,7 +46,7 @@ SIGNATURES["emdr2_assemble_evidence"] = (_i32, [_vp, _vp, _i32, _i32, _i32, _vp,
 _f32 = ctypes.c_float
 _u32 = ctypes.c_uint32
 SIGNATURES["emdr2_gemm_nt_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i32, _i64, _i64, _i64,
-                                             _f32, _vp, _i32, _vp, _vp, _i32, _i32, _f32, _u32, _vp])
+                                             _f32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _f32, _u32, _vp])
 SIGNATURES["emdr2_gemm_tn_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp])
 SIGNATURES["emdr2_dropout"] = (_i32, [_vp, _vp, _i64, _i32, _f32, _u32, _vp])
 SIGNATURES["emdr2_transpose_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _i64, _i64, _i32, _i64, _i64, _vp, _vp])

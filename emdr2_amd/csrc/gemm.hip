@@ -27,6 +27,7 @@ struct GemmParams {
     char *C, *C2;             // C2: optional pre-activation output (bf16)
     const float *bias;
     const char *R;            // optional residual (bf16, same indexing as C)
+    int rmode;                // 0: + R;  1: * gelu'(R) -- R is the saved GELU pre-activation (backward of the FFN's first linear, fused)
     long long lda, ldb, ldc;  // in elements
     long long sA1, sB1, sC1, sA2, sB2, sC2; // batch strides in elements
     int M, N, K, batch2;
@@ -65,6 +66,16 @@ __device__ __forceinline__ void store_stream(uint16_t *dst, uint4 v)
 {
     const u32x4_t x = {v.x, v.y, v.z, v.w};
     __builtin_nontemporal_store(x, (u32x4_t *)dst);
+}
+// d/dx of the erf-form GELU: Phi(x) + x phi(x), same erf approximation and the same exponential as the forward
+__device__ __forceinline__ float gelu_erf_grad(float x)
+{
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);          // exp(-x^2 / 2)
+    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-poly, e, 1.0f), x));
+    return fmaf(x * 0.3989422804014327f, e, cdf);
 }
 __device__ __forceinline__ float gelu_erf(float x)
 {
@@ -261,7 +272,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     if (p.R) {
                         const uint32_t rw[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) { v[2 * j] += bf16_to_f32((uint16_t)(rw[j] & 0xffff)); v[2 * j + 1] += bf16_to_f32((uint16_t)(rw[j] >> 16)); }
+                        for (int j = 0; j < 4; ++j) {
+                            const float r0 = bf16_to_f32((uint16_t)(rw[j] & 0xffff)), r1 = bf16_to_f32((uint16_t)(rw[j] >> 16));
+                            if (p.rmode == 0) { v[2 * j] += r0; v[2 * j + 1] += r1; }
+                            else { v[2 * j] *= gelu_erf_grad(r0); v[2 * j + 1] *= gelu_erf_grad(r1); }
+                        }
                     }
                     uint32_t w[4];
 #pragma unroll
@@ -293,7 +308,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                 if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
                 if (p.gelu) v = gelu_erf(v);
                 if (p.drop_p > 0.f) v = emdr2_keep(emdr2_row_hash(p.seed, (unsigned long long)m), (uint32_t)n, emdr2_drop_thr(p.drop_p)) ? v * emdr2_keep_scale(p.drop_p) : 0.f;
-                if (p.R) v += bf16_to_f32(((const uint16_t *)p.R)[o]);
+                if (p.R) { const float rv = bf16_to_f32(((const uint16_t *)p.R)[o]); v = p.rmode == 0 ? v + rv : v * gelu_erf_grad(rv); }
                 if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
                 else if (p.out_f32) ((float *)p.C)[o] = v;
                 else ((uint16_t *)p.C)[o] = f32_to_bf16(v);
@@ -335,8 +350,8 @@ static int launch_gemm(const GemmParams &p, int batch, hipStream_t stream)
 
 extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
                                   int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
-                                  float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
-                                  int split_k, float drop_p, uint32_t seed, void *stream)
+                                  float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int residual_mode,
+                                  int out_f32, int split_k, float drop_p, uint32_t seed, void *stream)
 {
     if (drop_p < 0.f || drop_p >= 1.f || (drop_p > 0.f && (batch1 * batch2 != 1 || split_k > 1))) return -1;
     if (!A || !B || !C || M < 1 || N < 1 || K < 32 || (K & 31) || batch1 < 1 || batch2 < 1 || split_k < 1) return -1;
@@ -345,7 +360,8 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     if ((sA1 & 7) || (sB1 & 7) || (sA2 & 7) || (sB2 & 7)) return -1;
     GemmParams p;
     p.A = (const char *)A; p.B = (const char *)B; p.C = (char *)C; p.C2 = (char *)pre_act;
-    p.bias = bias; p.R = (const char *)residual;
+    if (residual_mode != 0 && residual_mode != 1) return -1;
+    p.bias = bias; p.R = (const char *)residual; p.rmode = residual_mode;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
     p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k; p.drop_p = drop_p; p.seed = seed;

@@ -54,9 +54,9 @@ DROPOUT = _DropoutState()
 
 # ---- raw kernels --------------------------------------------------------------------------------------------------------
 def gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None,
-            gelu=False, pre_act=None, residual=None, split_k=1, drop_p=0.0, seed=0):
+            gelu=False, pre_act=None, residual=None, split_k=1, drop_p=0.0, seed=0, residual_mode=0):
     _native.check(_lib().emdr2_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, batch1, sA1, sB1, sC1, batch2, sA2,
-                                            sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual),
+                                            sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual), int(residual_mode),
                                             int(C.dtype == torch.float32), split_k, float(drop_p), int(seed), _sp()), "gemm_nt_bf16")
     return C
 
@@ -228,6 +228,62 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None, drop_p=0.0, seed=0):
     return LinearFn.apply(x, weight, bias, gelu, residual, row_perm, drop_p, seed)
+
+
+class MLPFn(torch.autograd.Function):
+    """ParallelMLP + bias-dropout-add as one node (transformer.py:58-108,397-413): y = residual + dropout(gelu(x W1^T + b1) W2^T + b2).
+    Fusing the two linears lets the backward fold gelu'(pre) into the epilogue of the GEMM that produces d(gelu output) instead of
+    running a separate 3 x [tokens, ffn] elementwise pass between two autograd nodes."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
+        _check_bf16(x, residual)
+        shp = x.shape
+        x2 = x.reshape(-1, shp[-1])
+        if not x2.is_contiguous():
+            raise ValueError("MLP input must be contiguous")
+        M, H = x2.shape
+        F = w1.shape[0]
+        pre = torch.empty((M, F), dtype=BF16, device=x.device)
+        inter = torch.empty((M, F), dtype=BF16, device=x.device)
+        gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
+        y = torch.empty((M, H), dtype=BF16, device=x.device)
+        gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=residual.reshape(M, H), drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x2, pre, inter)
+        ctx.params, ctx.shp, ctx.drop_p, ctx.seed = (w1, b1, w2, b2), shp, drop_p, seed
+        return y.reshape(shp)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, pre, inter = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        M, H = x2.shape
+        F = w1.shape[0]
+        if M % 32:
+            raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
+        dy2 = dy.reshape(M, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy
+        if ctx.drop_p > 0.0:
+            dmask = torch.empty_like(dy2)
+            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), H, ctx.drop_p, ctx.seed, _sp()), "dropout")
+            dy2 = dmask
+        # d(pre) = (dy W2) * gelu'(pre): the multiply rides in the GEMM epilogue
+        dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
+        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)
+        db2 = torch.zeros(H, dtype=torch.float32, device=dy.device)
+        _accum_grad(w2, weight_grad_tn(dy2, inter, colsum=db2))
+        _accum_grad(b2, db2)
+        dx = matmul_nt(dpre, w_bf16_t(w1)).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
+        db1 = torch.zeros(F, dtype=torch.float32, device=dy.device)
+        _accum_grad(w1, weight_grad_tn(dpre, x2, colsum=db1))
+        _accum_grad(b1, db1)
+        return dx, None, None, None, None, dres, None, None
+
+
+def mlp(x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
+    return MLPFn.apply(x, w1, b1, w2, b2, residual, drop_p, seed)
 
 
 class LayerNormFn(torch.autograd.Function):

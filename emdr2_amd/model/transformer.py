@@ -71,10 +71,10 @@ class ParallelMLP(torch.nn.Module):
         self.hidden_dropout, self._site = cfg.hidden_dropout, K.DROPOUT.new_site()
 
     def forward(self, x, residual):
-        inter = K.linear(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, gelu=True)          # bias + exact-erf GELU in the epilogue
         p = self.hidden_dropout if self.training else 0.0
-        return K.linear(inter, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, residual=residual,  # bias-dropout-add in the epilogue
-                        drop_p=p, seed=K.DROPOUT.seed(self._site) if p else 0)
+        # both linears, bias + erf-GELU, bias-dropout-add and (in the backward) gelu' in GEMM epilogues: one autograd node
+        return K.mlp(x, self.dense_h_to_4h.weight, self.dense_h_to_4h.bias, self.dense_4h_to_h.weight, self.dense_4h_to_h.bias, residual,
+                     drop_p=p, seed=K.DROPOUT.seed(self._site) if p else 0)
 
 
 class ParallelAttention(torch.nn.Module):

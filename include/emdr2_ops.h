@@ -22,12 +22,14 @@ extern "C" {
  * survivors are scaled by 1/(1-p); emdr2_dropout() applies the same mask to the incoming gradient in the backward.
  * K % 32 == 0; lda, ldb and the A/B batch strides multiples of 8 elements; A, B 16-byte aligned.
  * pre_act (optional, bf16, indexed like C): value before GELU, kept for the backward.
+ * residual_mode 0: + residual.  1: the `residual` buffer holds a saved GELU pre-activation u and the result is MULTIPLIED by gelu'(u) --
+ * the backward of bias-GELU fused into the GEMM that produces d(activation) (saves one 3 x [tokens, ffn] elementwise pass).
  * split_k > 1: the reduction is cut into split_k slices accumulated with fp32 atomics into a PRE-ZEROED fp32 C (weight
  * gradients: few output tiles, very long K); no epilogue options in that mode.
  */
 int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K,
                        int batch1, int64_t sA1, int64_t sB1, int64_t sC1, int batch2, int64_t sA2, int64_t sB2, int64_t sC2,
-                       float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int out_f32,
+                       float alpha, const float *bias, int gelu, void *pre_act, const void *residual, int residual_mode, int out_f32,
                        int split_k, float drop_p, uint32_t seed, void *stream);
 
 /* Weight-gradient GEMM, "TN" form: C[i, j] (fp32) = sum_r A[r, i] * B[r, j], A [R, I] and B [R, J] row-major bf16 (dW = dy^T x without

@@ -23,7 +23,7 @@ def _gemm(A, B, bias=None, gelu=False, residual=None, alpha=1.0, out_f32=False, 
     batch = int(np.prod(A.shape[:-2])) if A.dim() > 2 else 1
     nat.check(lib.emdr2_gemm_nt_bf16(A.data_ptr(), K, B.data_ptr(), K, C.data_ptr(), N, M, N, K, batch, M * K, (N * K if B.dim() > 2 else 0), M * N,
                                      1, 0, 0, 0, alpha, bias.data_ptr() if bias is not None else None, int(gelu),
-                                     pre.data_ptr() if pre is not None else None, residual.data_ptr() if residual is not None else None,
+                                     pre.data_ptr() if pre is not None else None, residual.data_ptr() if residual is not None else None, 0,
                                      int(out_f32), 1, 0.0, 0, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     return (C, pre) if want_pre else C
@@ -72,7 +72,7 @@ def test_gemm_batched_two_levels_strided():
     q, k = qkv[:, :, 0], qkv[:, :, 1]
     ld = 3 * heads * hn
     nat.check(lib.emdr2_gemm_nt_bf16(q.data_ptr(), ld, k.data_ptr(), ld, scores.data_ptr(), s, s, s, hn, b, s * ld, s * ld, heads * s * s,
-                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, 1, 0.0, 0, nat.stream_ptr()), "gemm")
+                                     heads, hn, hn, s * s, 0.125, None, 0, None, None, 0, 0, 1, 0.0, 0, nat.stream_ptr()), "gemm")
     torch.cuda.synchronize()
     ref = torch.einsum("bqnd,bknd->bnqk", q.float(), k.float()) * 0.125
     assert torch.allclose(scores.float(), ref, rtol=2e-2, atol=5e-2)
@@ -282,3 +282,30 @@ def test_layernorm_forward_backward_vs_torch(rows, H):
     rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
     assert rel(y, ref) < 1e-2
     assert rel(x.grad, xf.grad) < 2e-2 and rel(gamma.grad, gf.grad) < 2e-2 and rel(beta.grad, bf.grad) < 2e-2
+
+
+def test_fused_mlp_forward_backward_vs_torch():
+    """gelu(x W1^T + b1) W2^T + b2 with dropout and residual as one node; gelu' applied in the epilogue of the dy W2 GEMM."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(13)
+    M, H, F, p, seed = 512, 256, 1024, 0.1, 777
+    x = (torch.randn((M, H), generator=g, device="cuda")).bfloat16().requires_grad_(True)
+    res = torch.randn((M, H), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    W1 = torch.nn.Parameter(torch.randn((F, H), generator=g, device="cuda") * 0.08); b1 = torch.nn.Parameter(torch.randn(F, generator=g, device="cuda") * 0.5)
+    W2 = torch.nn.Parameter(torch.randn((H, F), generator=g, device="cuda") * 0.05); b2 = torch.nn.Parameter(torch.randn(H, generator=g, device="cuda") * 0.5)
+    y = K.mlp(x, W1, b1, W2, b2, res, drop_p=p, seed=seed)
+    w = torch.randn(y.shape, generator=g, device="cuda")
+    (y.float() * w).sum().backward()
+    mask = _dropout_mask((M, H), p, seed)
+    f = lambda t: t.detach().float().requires_grad_(True)
+    xf, rf = f(x), f(res)
+    W1f, W2f = W1.detach().bfloat16().float().requires_grad_(True), W2.detach().bfloat16().float().requires_grad_(True)
+    b1f, b2f = f(b1), f(b2)
+    inter = torch.nn.functional.gelu(xf @ W1f.T + b1f)
+    ref = (inter @ W2f.T + b2f) * mask + rf
+    (ref * w).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert rel(y, ref) < 2e-2
+    for name, a, r in (("dx", x.grad, xf.grad), ("dres", res.grad, rf.grad), ("dW1", W1.grad, W1f.grad), ("db1", b1.grad, b1f.grad),
+                       ("dW2", W2.grad, W2f.grad), ("db2", b2.grad, b2f.grad)):
+        assert rel(a, r) < 3e-2, (name, rel(a, r))
