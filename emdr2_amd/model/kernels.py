@@ -288,7 +288,9 @@ def mlp(x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, passthrough=False):
+        """passthrough: also return x itself as a second output (the residual stream).  Its gradient then arrives here instead of at an
+        autograd add node, and the backward kernel folds it into dx (one pass instead of LN-backward + a 3-tensor elementwise add)."""
         _check_bf16(x)
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
@@ -300,26 +302,34 @@ class LayerNormFn(torch.autograd.Function):
                                                  rows, H, eps, _sp()), "layernorm_fwd")
         ctx.save_for_backward(x2, mean, rstd)
         ctx.gamma, ctx.beta = gamma, beta
+        if passthrough:
+            return y.reshape(x.shape), x.view_as(x)
         return y.reshape(x.shape)
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dpass=None):
         x2, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.gamma, ctx.beta
         rows, H = x2.shape
         dy2 = dy.reshape(rows, H).contiguous()
+        dres = dpass.reshape(rows, H).contiguous() if dpass is not None else None
         dx = torch.empty_like(x2)
         dg = torch.zeros(H, dtype=torch.float32, device=dy.device)
         db = torch.zeros_like(dg)
-        _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), None,
+        _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
                                                  dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
         _accum_grad(gamma, dg)
         _accum_grad(beta, db)
-        return dx.reshape(dy.shape), None, None, None
+        return dx.reshape(dy.shape), None, None, None, None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def layer_norm_residual(x, gamma, beta, eps=1e-5):
+    """(LayerNorm(x), x): use the second output as the residual operand of the block that consumes the first."""
+    return LayerNormFn.apply(x, gamma, beta, eps, True)
 
 
 class _AttentionStash(object):

@@ -52,7 +52,9 @@ class LayerNorm(torch.nn.Module):
         self.bias = torch.nn.Parameter(torch.zeros(h, dtype=torch.float32, device="cuda"))
         self.eps = eps
 
-    def forward(self, x):
+    def forward(self, x, with_residual=False):
+        if with_residual:
+            return K.layer_norm_residual(x, self.weight, self.bias, self.eps)
         return K.layer_norm(x, self.weight, self.bias, self.eps)
 
 
@@ -128,11 +130,13 @@ class ParallelTransformerLayer(torch.nn.Module):
         self.mlp = ParallelMLP(cfg, out_std)
 
     def forward(self, x, ids, causal, encoder_output=None, enc_ids=None):
-        x = self.self_attention(self.input_layernorm(x), ids, ids, causal, residual=x)
-        ln = self.post_attention_layernorm(x)
+        # every LayerNorm hands the residual stream through, so the stream's gradient is folded into the LayerNorm backward kernel
+        ln, x = self.input_layernorm(x, with_residual=True)
+        x = self.self_attention(ln, ids, ids, causal, residual=x)
+        ln, x = self.post_attention_layernorm(x, with_residual=True)
         if self.layer_type == "decoder":
             x = self.inter_attention(ln, ids, enc_ids, False, residual=x, encoder_output=encoder_output)
-            ln = self.post_inter_attention_layernorm(x)
+            ln, x = self.post_inter_attention_layernorm(x, with_residual=True)
         return self.mlp(ln, residual=x)
 
 
