@@ -132,8 +132,8 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
     if (carve((char *)workspace, dim, &w) > workspace_bytes) return EMDR2_E_WORKSPACE;
     hipStream_t stream = (hipStream_t)stream_;
     const int kp = k <= 56 ? 64 : 128;
-    const int seg0 = env_int("EMDR2_MIPS_SEG0", 2048) / 512 * 512;
-    const int growth = env_int("EMDR2_MIPS_GROWTH", 32);
+    const int seg0 = env_int("EMDR2_MIPS_SEG0", 8192) / 512 * 512;
+    const int growth = env_int("EMDR2_MIPS_GROWTH", 16);
     if (seg0 < 512 || seg0 > (int)CAPQ - 512 || growth < 2) return EMDR2_E_BADARG;
     const int force_variant = env_int("EMDR2_MIPS_VARIANT", -1);
     const int cus = env_int("EMDR2_MIPS_GRID", cu_count());
