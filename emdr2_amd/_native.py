@@ -91,6 +91,10 @@ def lib():
     """Load (once) and return the ctypes handle; raises NativeError when the library is absent."""
     global _lib
     if _lib is None:
+        # torch first: PyTorch-ROCm ships its own libamdhip64; if this library were loaded before it, the dynamic linker would bind us to
+        # the system HIP runtime and torch to its bundled one -- two runtimes in one process, torch's device pointers invalid in ours
+        # (seen as "HIP launch/runtime error" on the first kernel when build() and smoke() ran in one interpreter).
+        import torch  # noqa: F401
         if not os.path.exists(LIB_PATH):
             raise NativeError(
                 "libemdr2_hip.so not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` "
