@@ -114,7 +114,5 @@ def parse_args(argv=None):
         raise ValueError("kv-channels * num-attention-heads must equal hidden-size")
     if args.eval_batch_size is None:
         args.eval_batch_size = args.batch_size
-    if args.no_query_embedder_training or args.no_context_embedder_training:
-        raise NotImplementedError("--no-query/context-embedder-training are not used by the shipped scripts and not built")
     args.iteration = 0
     return args

@@ -113,7 +113,8 @@ class EMDR2Model(torch.nn.Module):
     kernels, so `query_mask_bert` is accepted for signature compatibility and ignored."""
 
     def __init__(self, evidence_retriever, cfg, t5_vocab_size, bert_vocab_size, topk, seq_length, seq_length_ret, cls_id, sep_id, pad_id=0,
-                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False, disable_retriever_dropout=False):
+                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False, disable_retriever_dropout=False,
+                 no_query_embedder_training=False, no_context_embedder_training=False):
         super().__init__()
         self.topk = topk
         self.language_model = T5Model(cfg, t5_vocab_size, 2, checkpoint_activations)
@@ -126,6 +127,8 @@ class EMDR2Model(torch.nn.Module):
         self.cls_id, self.sep_id, self.pad_id = cls_id, sep_id, pad_id
         self.update_retriever, self.retriever_score_scaling = update_retriever, retriever_score_scaling
         self.disable_retriever_dropout = disable_retriever_dropout                  # --disable-retriever-dropout (arguments.py:558)
+        self.no_query_embedder_training = no_query_embedder_training              # emdr2_model.py:103-104
+        self.no_context_embedder_training = no_context_embedder_training          # emdr2_model.py:130-131
 
     def retriever_embedder(self, tokens, mask, types, embedder_type, disable_dropout=False):
         tower = self.retriever_model.query_model if embedder_type == "query" else self.retriever_model.context_model
@@ -142,6 +145,8 @@ class EMDR2Model(torch.nn.Module):
             lm_logits = self.language_model.decode(dec_ids, all_query_context_hidden_states, all_query_context_ids_unflat)
             return lm_logits, topk_log_probs, all_query_context_hidden_states, all_query_context_ids_unflat
         query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query", self.disable_retriever_dropout)
+        if self.no_query_embedder_training:
+            query_logits = query_logits.detach()
         with torch.no_grad():                                            # emdr2_model.py:107-115 on the device
             ctx_ids, ctx_types, qext, qone, _, _ = self.evidence_retriever.get_topk_assembled(
                 query_logits.detach(), query_uid, query_ids_t5, query_ids_t5_len, self.cls_id, self.sep_id, self.pad_id)
@@ -152,6 +157,8 @@ class EMDR2Model(torch.nn.Module):
         H = self.hidden_size
         ctx_logits = self.retriever_embedder(ctx_ids.reshape(B * Kk, -1), None, ctx_types.reshape(B * Kk, -1), "context",
                                              self.disable_retriever_dropout).reshape(B, Kk, H)
+        if self.no_context_embedder_training:
+            ctx_logits = ctx_logits.detach()
         # fresh retriever scores (emdr2_model.py:134-145): 2*B*K*H flop, negligible; kept in torch fp32 on purpose
         sim = torch.bmm(query_logits.unsqueeze(1).float(), ctx_logits.float().transpose(1, 2))
         if self.retriever_score_scaling:

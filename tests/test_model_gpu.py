@@ -229,3 +229,29 @@ def test_attention_stash_under_checkpointing_gives_identical_gradients():
         grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     for k in grads[0]:
         assert _rel(grads[1][k], grads[0][k]) < 1e-3, k
+
+
+def test_embedder_training_switches_cut_the_gradient_of_one_tower():
+    """--no-query-embedder-training / --no-context-embedder-training (emdr2_model.py:103-104,130-131): the tower's output is detached."""
+    from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
+    from emdr2_amd.model.transformer import Config
+    rng = np.random.default_rng(8)
+    cfg = Config(num_layers=1, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=64, init_method_std=0.05)
+    for no_q, no_c in ((True, False), (False, True)):
+        torch.manual_seed(0)
+        m = EMDR2Model(None, cfg, 512, 512, 2, 64, 32, cls_id=2, sep_id=3, no_query_embedder_training=no_q, no_context_embedder_training=no_c).train()
+        B, K = 32, 2
+        q_ids = _ids(rng, (B, 32), 512).cuda()
+        ctx = _ids(rng, (B, K, 32), 512).cuda()
+        qext = _ids(rng, (B * K, 64), 512).cuda(); qone = _ids(rng, (B * K, 64), 512).cuda()
+        dec = _ids(rng, (B, 32), 512).cuda()
+        ql = m.retriever_embedder(q_ids, None, torch.zeros_like(q_ids), "query")
+        if no_q:
+            ql = ql.detach()
+        lm, tlp, one = m.forward_assembled(ql, ctx, torch.zeros_like(ctx), qext, qone, dec)
+        labels = torch.roll(dec, -1, 1)
+        loss, _ = emdr2_loss(lm, tlp, one, labels, (labels != 0).float(), eos_id=511)
+        loss.backward()
+        gq = [p.grad for p in m.retriever_model.query_model.parameters() if p.grad is not None]
+        gc = [p.grad for p in m.retriever_model.context_model.parameters() if p.grad is not None]
+        assert (len(gq) == 0) == no_q and (len(gc) == 0) == no_c
