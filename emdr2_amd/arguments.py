@@ -81,6 +81,7 @@ def get_parser():
     g.add_argument('--emdr2-training', action='store_true')
     g.add_argument('--retriever-score-scaling', action='store_true')
     g.add_argument('--update-retriever', action='store_true')
+    g.add_argument('--ret-kldiv', action='store_true')
     g.add_argument('--allow-trivial-doc', action='store_true')
     g.add_argument('--disable-retriever-dropout', action='store_true')
     g.add_argument('--no-query-embedder-training', action='store_true')

@@ -205,7 +205,7 @@ class EMDR2Model(torch.nn.Module):
         checkpointing.load_dualencoder_checkpoint(self.retriever_model, pretrained_dpr_load)
 
 
-def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id):
+def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id, ret_kldiv=False):
     """_cross_entropy_forward_step + get_loss_and_retriever_utility (tasks/openqa/e2eqa/train_e2eqa.py:72-181).
     The two vocabulary-sized log-softmax + gather passes run in the HIP kernel; what is left in torch acts on [B,L] / [B,K,L]."""
     mask = loss_mask.float()
@@ -217,6 +217,11 @@ def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_ma
         Kk = lm_logits_one_context.shape[1]
         lab = labels.masked_fill(~loss_mask.to(torch.bool), 0)
         gold1 = K.lse_gather(lm_logits_one_context, lab.unsqueeze(1).expand(-1, Kk, -1).contiguous()).detach()   # [B, K, L]
+        if ret_kldiv:                                                                         # --ret-kldiv (train_e2eqa.py:184-214)
+            teacher_log = torch.sum(gold1 * mask.unsqueeze(1), dim=2) / torch.sum(mask.unsqueeze(1), dim=2)
+            retriever_loss = torch.nn.functional.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='batchmean')
+            stats["retriever_loss"] = retriever_loss.detach()
+            return lm_loss + retriever_loss, stats
         marginal = torch.logsumexp(topk_log_probs.float().unsqueeze(-1) + gold1, dim=1)
         retriever_loss = -torch.sum(marginal * mask) / mask.sum()
         util_mask = mask.masked_fill(lab >= eos_id, 0)

@@ -28,7 +28,11 @@ def _cross_entropy_forward_step(batch, model, eos_id):
     query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids, labels, loss_mask, _ = process_batch(batch_)
     assert torch.all(query_uid < 0), "query uid can't be positive"
     lm_logits, topk_log_probs, lm_logits_one_context = model(query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids)
-    net_loss, stats = emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id)
+    try:
+        ret_kldiv = bool(getattr(get_args(), 'ret_kldiv', False))
+    except RuntimeError:
+        ret_kldiv = False
+    net_loss, stats = emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id, ret_kldiv=ret_kldiv)
     return net_loss, {'lm_loss': stats['lm_loss'], 'retriever_loss': stats['retriever_loss']}
 
 

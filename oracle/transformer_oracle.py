@@ -166,6 +166,17 @@ def retriever_loss_and_utility(one_context_logits, topk_log_probs, labels, loss_
     return loss, utility, null_loss
 
 
+def retriever_kl_div_loss(one_context_logits, topk_log_probs, labels, loss_mask):
+    """--ret-kldiv variant (train_e2eqa.py:184-214): KL(teacher || retriever prior), teacher = softmax over K of the length-normalised
+    gold log-likelihood under each single-context reader pass."""
+    logp = F.log_softmax(one_context_logits.float(), dim=-1)
+    labels = labels.masked_fill(~loss_mask.to(torch.bool), 0)
+    K = one_context_logits.shape[1]
+    gold = torch.gather(logp, -1, labels[:, None, :, None].expand(-1, K, -1, 1)).squeeze(-1)
+    teacher_log = torch.sum(gold * loss_mask.unsqueeze(1), dim=2) / torch.sum(loss_mask.unsqueeze(1), dim=2)
+    return F.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='batchmean')
+
+
 def annealing_lr(num_iters, start_lr, warmup_iter, end_iter, min_lr=0.0):
     """AnnealingLR.get_lr with decay_style 'linear' (learning_rates.py:51-71), incl. its clamp quirk."""
     n_ = min(num_iters, end_iter - warmup_iter)

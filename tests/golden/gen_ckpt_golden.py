@@ -37,7 +37,17 @@ def main():
     pairs = [("The Eiffel Tower", ["eiffel tower"]), ("an  apple, a day!", ["Apple day"]), ("Paris", ["London", "paris."]), ("1999", ["1,999"]),
              ("new-york", ["new york"]), ("", ["the"]), ("A", ["b"])]
     em = [bool(metric_max_over_ground_truths(exact_match_score, h, r)) for h, r in pairs]
-    json.dump({"layout": out, "em_pairs": pairs, "em": em}, open(os.path.join(HERE, "ckpt_layout.json"), "w"), indent=0)
+    # --ret-kldiv retriever loss (train_e2eqa.py:184-214) on small random inputs
+    from tasks.openqa.e2eqa.train_e2eqa import get_kl_div_retriever
+    gen = torch.Generator().manual_seed(7)
+    B, K, L, V = 3, 4, 6, 11
+    one = torch.randn((B, K, L, V), generator=gen)
+    tlp = torch.log_softmax(torch.randn((B, K), generator=gen), dim=1)
+    labels = torch.randint(1, V, (B, L), generator=gen)
+    mask = (torch.rand((B, L), generator=gen) > 0.3).float(); mask[:, 0] = 1.0
+    kl = get_kl_div_retriever(one, tlp, labels, mask)
+    kl_case = {"one": one.tolist(), "tlp": tlp.tolist(), "labels": labels.tolist(), "mask": mask.tolist(), "loss": float(kl)}
+    json.dump({"layout": out, "em_pairs": pairs, "em": em, "kl": kl_case}, open(os.path.join(HERE, "ckpt_layout.json"), "w"), indent=0)
     print(len(out), em)
 
 

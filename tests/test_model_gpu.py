@@ -255,3 +255,23 @@ def test_embedder_training_switches_cut_the_gradient_of_one_tower():
         gq = [p.grad for p in m.retriever_model.query_model.parameters() if p.grad is not None]
         gc = [p.grad for p in m.retriever_model.context_model.parameters() if p.grad is not None]
         assert (len(gq) == 0) == no_q and (len(gc) == 0) == no_c
+
+
+def test_kl_div_retriever_loss_variant_vs_oracle():
+    """--ret-kldiv (train_e2eqa.py:163-169,184-214): value and the gradient it sends into the retriever prior."""
+    from emdr2_amd.model.emdr2_model import emdr2_loss
+    g = torch.Generator(device="cuda").manual_seed(5)
+    B, K, L, V = 4, 3, 8, 64
+    lm = torch.randn((B, L, V), generator=g, device="cuda").bfloat16()
+    one = torch.randn((B, K, L, V), generator=g, device="cuda").bfloat16()
+    tl = torch.randn((B, K), generator=g, device="cuda", requires_grad=True)
+    labels = torch.randint(1, V, (B, L), generator=g, device="cuda")
+    mask = (torch.rand((B, L), generator=g, device="cuda") > 0.3).float(); mask[:, 0] = 1
+    tlp = torch.log_softmax(tl, dim=1)
+    loss, stats = emdr2_loss(lm, tlp, one, labels, mask, eos_id=V - 1, ret_kldiv=True)
+    loss.backward()
+    tl_r = tl.detach().cpu().clone().requires_grad_(True)
+    ref = to.retriever_kl_div_loss(one.float().cpu(), torch.log_softmax(tl_r, dim=1), labels.cpu(), mask.cpu())
+    ref.backward()
+    assert abs(float(stats["retriever_loss"]) - float(ref)) < 1e-3 * max(1.0, abs(float(ref)))
+    assert _rel(tl.grad.cpu(), tl_r.grad) < 1e-3

@@ -63,3 +63,11 @@ def test_learning_rate_table():
     g = mf.load()[0]
     ours = [to.annealing_lr(i + 1, 2e-5, 10, 1000) for i in range(1000)]
     np.testing.assert_allclose(ours, g["lr_table"], rtol=1e-12, atol=0)
+
+
+def test_kl_div_retriever_loss_matches_reference():
+    import json
+    import os
+    ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ckpt_layout.json")))["kl"]
+    got = to.retriever_kl_div_loss(torch.tensor(ref["one"]), torch.tensor(ref["tlp"]), torch.tensor(ref["labels"]), torch.tensor(ref["mask"]))
+    assert abs(float(got) - ref["loss"]) < 1e-6 * max(1.0, abs(ref["loss"]))
