@@ -47,6 +47,9 @@ def get_parser():
     g.add_argument('--load', type=str, default=None)
     g.add_argument('--no-save-optim', action='store_true')
     g.add_argument('--no-load-optim', action='store_true')
+    g.add_argument('--pretrained-checkpoint', type=str, default=None)
+    g.add_argument('--ict-load', type=str, default=None)
+    g.add_argument('--exit-interval', type=int, default=None)
     g.add_argument('--pretrained-t5-load', type=str, default=None)
     g.add_argument('--pretrained-dpr-load', type=str, default=None)
     g.add_argument('--stale-checkpoint-path', type=str, default=None)
@@ -73,6 +76,7 @@ def get_parser():
     g = p.add_argument_group('task (tasks/run.py)')
     g.add_argument('--task', type=str, required=True)
     g.add_argument('--epochs', type=int, default=None)
+    g.add_argument('--keep-last', action='store_true')
     g.add_argument('--train-data', nargs='+', default=None)
     g.add_argument('--valid-data', nargs='*', default=None)
     g.add_argument('--test-data', nargs='*', default=None)
@@ -115,5 +119,7 @@ def parse_args(argv=None):
         raise ValueError("kv-channels * num-attention-heads must equal hidden-size")
     if args.eval_batch_size is None:
         args.eval_batch_size = args.batch_size
+    if args.load and args.ict_load:
+        raise ValueError("--load and --ict-load are exclusive (indexer_emdr2.py:47)")
     args.iteration = 0
     return args

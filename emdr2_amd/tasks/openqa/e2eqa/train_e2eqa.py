@@ -199,6 +199,11 @@ def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_o
             if args.eval_interval and iteration % args.eval_interval == 0 and end_of_epoch_callback is not None:
                 end_of_epoch_callback(model, iteration)
                 end_of_epoch_callback2(model, iteration)
+            if args.exit_interval and iteration % args.exit_interval == 0:                    # train_e2eqa.py:526-540
+                print_rank_0('exiting the program at iteration {}'.format(iteration))
+                if args.save:
+                    _save(iteration, model, optimizer, lr_scheduler)
+                return iteration
         if args.save:
             _save(iteration, model, optimizer, lr_scheduler)
         if end_of_epoch_callback is not None:
@@ -214,7 +219,7 @@ def train(train_valid_datasets_provider, model_provider, forward_step=_cross_ent
     train_dataloader = None
     if args.epochs > 0:
         train_dataset, valid_dataset = train_valid_datasets_provider()
-        train_dataloader = build_data_loader(train_dataset, args.batch_size, args.num_workers, drop_last=True)
+        train_dataloader = build_data_loader(train_dataset, args.batch_size, args.num_workers, drop_last=not args.keep_last)
         args.train_iters_per_epoch = len(train_dataloader)
         args.train_iters = args.epochs * args.train_iters_per_epoch
     else:
@@ -223,6 +228,8 @@ def train(train_valid_datasets_provider, model_provider, forward_step=_cross_ent
     if args.epochs > 0 and end_of_epoch_callback_provider is not None:
         cb1, cb2 = end_of_epoch_callback_provider(args.valid_data), end_of_epoch_callback_provider(args.test_data)
     model, optimizer, lr_scheduler = setup_model_and_optimizer(model_provider)
+    if args.iteration == 0 and args.pretrained_checkpoint is not None:                     # train_e2eqa.py:586-593: weights only
+        checkpointing.load_checkpoint(args.pretrained_checkpoint, model, None, None)
     print_rank_0('done with setups ...')
     print_rank_0('training ...')
     if args.epochs > 0 and args.emdr2_training:
