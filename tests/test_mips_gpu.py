@@ -209,3 +209,32 @@ def test_index_from_flat_embedding_file_equals_index_from_the_pickle_store(tmp_p
     db, ib = b.search_mips_index(q, case["k"])
     assert torch.equal(da.view(torch.int16), db.view(torch.int16)) and torch.equal(ia, ib)
     assert flat.n == case["rows"].shape[0]
+
+
+def test_random_shapes_property_vs_oracle():
+    """Seeded sweep over random (rows, dim, queries, k, row_base, value scale, duplicate rows): canonical fp16 and fp32-score searches must
+    equal the exact-arithmetic oracle bit for bit on every one."""
+    rng = np.random.default_rng(20260928)
+    for case in range(24):
+        n = int(rng.integers(1, 6000))
+        dim = int(rng.integers(2, 33)) * 32
+        nq = int(rng.integers(1, 48))
+        k = int(rng.integers(1, 121))
+        base = int(rng.integers(0, 1 << 20))
+        scale = float(rng.choice([0.01, 0.25, 1.0, 4.0]))
+        rows = (rng.standard_normal((n, dim)) * scale).astype(np.float16)
+        if n > 10 and case % 3 == 0:                                    # exact duplicates: ties that only the row order can break
+            rows[rng.integers(0, n, size=n // 4)] = rows[rng.integers(0, n, size=n // 4)]
+        q = (rng.standard_normal((nq, dim)) * scale).astype(np.float16)
+        ids = (rng.permutation(n) + 1).astype(np.int32)
+        sh = _shard(rows, ids, row_base=base)
+        d, i, r, f = _search(sh, q, k)
+        od, oi, orow = mo.topk(rows, q, k, ids=ids, row_base=base, return_rows=True)
+        assert (f == 0).all(), case
+        assert_bit_identical(d, i, od, oi)
+        assert np.array_equal(r, orow), case
+        d32, i32, _, f32 = sh.search_f32(torch.from_numpy(q).cuda(), k)
+        od32, oi32 = mo.topk_f32(rows, q, k, ids=ids.astype(np.int64))
+        assert (f32.cpu().numpy() == 0).all(), case
+        assert np.array_equal(d32.cpu().numpy().view(np.uint32), np.ascontiguousarray(od32).view(np.uint32)), case
+        assert np.array_equal(i32.cpu().numpy().astype(np.int64), oi32), case
