@@ -309,3 +309,50 @@ def test_fused_mlp_forward_backward_vs_torch():
     for name, a, r in (("dx", x.grad, xf.grad), ("dres", res.grad, rf.grad), ("dW1", W1.grad, W1f.grad), ("db1", b1.grad, b1f.grad),
                        ("dW2", W2.grad, W2f.grad), ("db2", b2.grad, b2f.grad)):
         assert rel(a, r) < 3e-2, (name, rel(a, r))
+
+
+def test_gemm_random_shapes_and_epilogues_property():
+    """Seeded sweep: ragged M / N (tile tails, XCD-remapped 1-D grids included), K multiples of 32, random epilogue combinations, NT and TN."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(7)
+    g = torch.Generator(device="cuda").manual_seed(7)
+    for case in range(20):
+        M = int(rng.integers(1, 5000)); N = int(rng.integers(1, 200)) * 8; Kd = int(rng.integers(1, 24)) * 32
+        a = (torch.randn((M, Kd), generator=g, device="cuda") * 0.5).bfloat16()
+        b = (torch.randn((N, Kd), generator=g, device="cuda") * 0.2).bfloat16()
+        use_bias, use_gelu, use_res = bool(rng.integers(0, 2)), bool(rng.integers(0, 2)), bool(rng.integers(0, 2))
+        alpha = float(rng.choice([1.0, 0.125]))
+        bias = torch.randn(N, generator=g, device="cuda") if use_bias else None
+        res = torch.randn((M, N), generator=g, device="cuda").bfloat16() if use_res else None
+        out = K.matmul_nt(a, b, alpha=alpha, bias=bias, gelu=use_gelu, residual=res)
+        ref = alpha * (a.float() @ b.float().T)
+        if use_bias:
+            ref = ref + bias
+        if use_gelu:
+            ref = torch.nn.functional.gelu(ref)
+        if use_res:
+            ref = ref + res.float()
+        err = float((out.float() - ref).abs().max() / (ref.abs().max() + 1e-6))
+        assert err < 2e-2, (case, M, N, Kd, use_bias, use_gelu, use_res, err)
+    for case in range(8):
+        R = int(rng.integers(1, 300)) * 32; I = int(rng.integers(1, 120)) * 8; J = int(rng.integers(1, 120)) * 8
+        dy = torch.randn((R, I), generator=g, device="cuda").bfloat16(); x = torch.randn((R, J), generator=g, device="cuda").bfloat16()
+        cs = torch.zeros(I, device="cuda")
+        dw = K.weight_grad_tn(dy, x, colsum=cs)
+        ref = dy.float().T @ x.float()
+        assert torch.allclose(dw, ref, rtol=2e-3, atol=2e-3 * R ** 0.5), (case, R, I, J)
+        assert torch.allclose(cs, dy.float().sum(0), rtol=1e-3, atol=1e-3 * R ** 0.5)
+
+
+def test_attention_random_shapes_property():
+    """Seeded sweep over (batch, heads, sq, sk, causal, dropout): fused and composed paths, forward and all input gradients, vs fp32 torch."""
+    rng = np.random.default_rng(11)
+    for case in range(12):
+        b, heads = int(rng.integers(1, 4)), int(rng.integers(1, 4))
+        if rng.integers(0, 2):
+            sq = sk = int(rng.integers(1, 9)) * 32
+        else:
+            sq, sk = int(rng.integers(1, 5)) * 32, int(rng.integers(1, 12)) * 64
+        causal = bool(sq == sk and rng.integers(0, 2))
+        drop = float(rng.choice([0.0, 0.1]))
+        _attention_case(b, heads, sq, sk, causal, drop, 1000 + case, 50 + case)
