@@ -244,18 +244,25 @@ class MLPFn(torch.autograd.Function):
             raise ValueError("MLP input must be contiguous")
         M, H = x2.shape
         F = w1.shape[0]
-        pre = torch.empty((M, F), dtype=BF16, device=x.device)
+        # the pre-activation is only needed by a backward that will really run from THIS forward: not in no-grad passes (the one-context
+        # pass, evaluation) and not in the first run of a checkpointed layer, whose saved tensors are dropped and rebuilt by the re-run
+        need_pre = any(ctx.needs_input_grad) and ATTN_STASH.mode != 'store'
+        pre = torch.empty((M, F), dtype=BF16, device=x.device) if need_pre else None
         inter = torch.empty((M, F), dtype=BF16, device=x.device)
         gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
         y = torch.empty((M, H), dtype=BF16, device=x.device)
         gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=residual.reshape(M, H), drop_p=drop_p, seed=seed)
-        ctx.save_for_backward(x2, pre, inter)
+        # (a placeholder keeps the NUMBER of saved tensors equal between a checkpointed layer's first run and its re-run, which is how
+        # torch.utils.checkpoint pairs them up)
+        ctx.save_for_backward(x2, pre if pre is not None else x2.new_empty(0), inter)
         ctx.params, ctx.shp, ctx.drop_p, ctx.seed = (w1, b1, w2, b2), shp, drop_p, seed
         return y.reshape(shp)
 
     @staticmethod
     def backward(ctx, dy):
         x2, pre, inter = ctx.saved_tensors
+        if pre.numel() == 0:
+            raise RuntimeError("MLP backward without the saved pre-activation (forward ran in a mode that does not keep it)")
         w1, b1, w2, b2 = ctx.params
         M, H = x2.shape
         F = w1.shape[0]
