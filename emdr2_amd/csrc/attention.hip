@@ -29,7 +29,7 @@ struct AttnParams {
     float *m, *l;
     long long q_sb, q_ss, q_sn;   // element strides of q: batch, sequence, head
     long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
-    int heads, sq, sk, causal;
+    int heads, sq, sk, causal, batch;
     float scale, drop_p;
     uint32_t seed;
 };
@@ -46,8 +46,9 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, n = blockIdx.y;
-    const int q0 = blockIdx.x * QB + wave * QW;
+    int qblk, b, n;
+    if (!attn_decode(blockIdx.x, (p.sq + QB - 1) / QB, p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const int q0 = qblk * QB + wave * QW;
     const int qi = q0 + l31;                       // this lane's query
     const bool qvalid = qi < p.sq;
     const int qc = qvalid ? qi : p.sq - 1;
@@ -241,7 +242,8 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.ids_q = (const long long *)ids_q; p.ids_k = (const long long *)ids_k; p.m = m; p.l = l;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
-    dim3 grid((sq + QB - 1) / QB, heads, batch);
+    p.batch = batch;
+    dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads));
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -35,7 +35,7 @@ struct BwdParams {
     long long q_sb, q_ss, q_sn;    // element strides of q (batch, sequence, head); k and v share k_*
     long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
     long long dq_sb, dq_ss, dkv_sb, dkv_ss;   // element strides (batch, sequence) of the gradient outputs; heads are 64 apart
-    int heads, sq, sk, causal;
+    int heads, sq, sk, causal, batch;
     float scale, drop_p;
     uint32_t seed;
 };
@@ -48,8 +48,9 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, n = blockIdx.y;
-    const int q0 = blockIdx.x * 256 + wave * 32;
+    int qblk, b, n;
+    if (!attn_decode(blockIdx.x, (p.sq + 255) / 256, p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const int q0 = qblk * 256 + wave * 32;
     const int qi = q0 + l31;
     const bool qvalid = qi < p.sq;
     const int qc = qvalid ? qi : p.sq - 1;
@@ -199,8 +200,9 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, n = blockIdx.y;
-    const int k0 = blockIdx.x * 256 + wave * 32;
+    int kblk, b, n;
+    if (!attn_decode(blockIdx.x, (p.sk + 255) / 256, p.batch * p.heads, p.heads, kblk, b, n)) return;
+    const int k0 = kblk * 256 + wave * 32;
     const int key = k0 + l31;
     const bool wave_live = k0 < p.sk;                                   // sk % 64 == 0: a wave's 32 keys are all valid or all out of range
     const int kc = wave_live ? key : p.sk - 1;
@@ -373,7 +375,8 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dkv_sb = dkv_sb; p.dkv_ss = dkv_ss;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3((sq + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3((sk + 255) / 256, heads, batch), dim3(512), 0, (hipStream_t)stream, p);
+    p.batch = batch;
+    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(attn_grid((sq + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(attn_grid((sk + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -67,4 +67,17 @@ __device__ __forceinline__ void tr_addresses(uint32_t tile_lds, int lane, uint32
         dst = __builtin_bit_cast(bf16x8, make_uint4(lo_.x, lo_.y, hi_.x, hi_.y));          \
     } while (0)
 
+// 1-D grid decode shared by the attention kernels: workgroup ids go round-robin to the 8 XCDs (one L2 each); the blocks of one (batch,
+// head) -- which stream the same K/V (or Q/dO) rows -- are given ids 8 apart so they land on the SAME XCD and the shared operand leaves HBM
+// once.  ids: xcd = id & 7, rest = id >> 3, block = rest % nblk, bn = (rest / nblk) * 8 + xcd; returns false for the padded tail.
+__device__ __forceinline__ bool attn_decode(int id, int nblk, int total_bn, int heads, int &blk, int &b, int &n)
+{
+    const int xcd = id & 7, rest = id >> 3;
+    blk = rest % nblk;
+    const int bn = (rest / nblk) * 8 + xcd;
+    if (bn >= total_bn) return false;
+    b = bn / heads; n = bn - b * heads;
+    return true;
+}
+__host__ __forceinline__ unsigned attn_grid(int nblk, int total_bn) { return (unsigned)(((total_bn + 7) / 8) * 8 * nblk); }
 #endif
