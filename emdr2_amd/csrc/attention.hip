@@ -193,18 +193,17 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
             }
             const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
             // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile) by transpose reads
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x8 vt;
-                const uint32_t av[2] = {vtr[j][0] + (uint32_t)(stage * 16384), vtr[j][1] + (uint32_t)(stage * 16384)};
-                switch (u) {
-                case 0: TR_FRAG(vt, av, 0); break;
-                case 1: TR_FRAG(vt, av, 1); break;
-                case 2: TR_FRAG(vt, av, 2); break;
-                default: TR_FRAG(vt, av, 3); break;
-                }
-                oacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt, pf, oacc[j], 0, 0, 0);
+            bf16x8 vt0, vt1;
+            const uint32_t av0[2] = {vtr[0][0] + (uint32_t)(stage * 16384), vtr[0][1] + (uint32_t)(stage * 16384)};
+            const uint32_t av1[2] = {vtr[1][0] + (uint32_t)(stage * 16384), vtr[1][1] + (uint32_t)(stage * 16384)};
+            switch (u) {
+            case 0: TR_FRAG2(vt0, av0, vt1, av1, 0); break;
+            case 1: TR_FRAG2(vt0, av0, vt1, av1, 1); break;
+            case 2: TR_FRAG2(vt0, av0, vt1, av1, 2); break;
+            default: TR_FRAG2(vt0, av0, vt1, av1, 3); break;
             }
+            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, pf, oacc[0], 0, 0, 0);
+            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
         }
     }
 

@@ -162,18 +162,17 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
                                                                       pack_bf16(sacc[u >> 1][r0 + 2], sacc[u >> 1][r0 + 3]),
                                                                       pack_bf16(sacc[u >> 1][r0 + 4], sacc[u >> 1][r0 + 5]),
                                                                       pack_bf16(sacc[u >> 1][r0 + 6], sacc[u >> 1][r0 + 7])));
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                bf16x8 kt;
-                const uint32_t a0[2] = {ktr[j][0] + (uint32_t)(stage * 16384), ktr[j][1] + (uint32_t)(stage * 16384)};
-                switch (u) {
-                case 0: TR_FRAG(kt, a0, 0); break;
-                case 1: TR_FRAG(kt, a0, 1); break;
-                case 2: TR_FRAG(kt, a0, 2); break;
-                default: TR_FRAG(kt, a0, 3); break;
-                }
-                dqacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt, dsf, dqacc[j], 0, 0, 0);
+            bf16x8 kt0, kt1;
+            const uint32_t a0[2] = {ktr[0][0] + (uint32_t)(stage * 16384), ktr[0][1] + (uint32_t)(stage * 16384)};
+            const uint32_t a1[2] = {ktr[1][0] + (uint32_t)(stage * 16384), ktr[1][1] + (uint32_t)(stage * 16384)};
+            switch (u) {
+            case 0: TR_FRAG2(kt0, a0, kt1, a1, 0); break;
+            case 1: TR_FRAG2(kt0, a0, kt1, a1, 1); break;
+            case 2: TR_FRAG2(kt0, a0, kt1, a1, 2); break;
+            default: TR_FRAG2(kt0, a0, kt1, a1, 3); break;
             }
+            dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dsf, dqacc[0], 0, 0, 0);
+            dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dsf, dqacc[1], 0, 0, 0);
         }
     }
     if (qvalid) {
@@ -321,20 +320,26 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
                                                                          pack_bf16(pacc[r0 + 4], pacc[r0 + 5]), pack_bf16(pacc[r0 + 6], pacc[r0 + 7])));
                 const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[r0], sacc[r0 + 1]), pack_bf16(sacc[r0 + 2], sacc[r0 + 3]),
                                                                           pack_bf16(sacc[r0 + 4], sacc[r0 + 5]), pack_bf16(sacc[r0 + 6], sacc[r0 + 7])));
-#pragma unroll
-                for (int jd = 0; jd < 2; ++jd) {
-                    bf16x8 ot, qt;
-                    const uint32_t ao[2] = {otr[jd][0] + (uint32_t)(stage * 16384), otr[jd][1] + (uint32_t)(stage * 16384)};
-                    const uint32_t aq[2] = {qtr[jd][0] + (uint32_t)(stage * 16384), qtr[jd][1] + (uint32_t)(stage * 16384)};
-                    switch (2 * j + uu) {
-                    case 0: TR_FRAG(ot, ao, 0); TR_FRAG(qt, aq, 0); break;
-                    case 1: TR_FRAG(ot, ao, 1); TR_FRAG(qt, aq, 1); break;
-                    case 2: TR_FRAG(ot, ao, 2); TR_FRAG(qt, aq, 2); break;
-                    default: TR_FRAG(ot, ao, 3); TR_FRAG(qt, aq, 3); break;
-                    }
-                    dvacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot, pf, dvacc[jd], 0, 0, 0);
-                    dkacc[jd] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt, dsf, dkacc[jd], 0, 0, 0);
+                bf16x8 ot0, ot1, qt0, qt1;
+                const uint32_t so = (uint32_t)(stage * 16384);
+                const uint32_t ao0[2] = {otr[0][0] + so, otr[0][1] + so}, ao1[2] = {otr[1][0] + so, otr[1][1] + so};
+                const uint32_t aq0[2] = {qtr[0][0] + so, qtr[0][1] + so}, aq1[2] = {qtr[1][0] + so, qtr[1][1] + so};
+                switch (2 * j + uu) {
+                case 0: TR_FRAG2(ot0, ao0, ot1, ao1, 0); break;
+                case 1: TR_FRAG2(ot0, ao0, ot1, ao1, 1); break;
+                case 2: TR_FRAG2(ot0, ao0, ot1, ao1, 2); break;
+                default: TR_FRAG2(ot0, ao0, ot1, ao1, 3); break;
                 }
+                dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot0, pf, dvacc[0], 0, 0, 0);
+                dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot1, pf, dvacc[1], 0, 0, 0);
+                switch (2 * j + uu) {
+                case 0: TR_FRAG2(qt0, aq0, qt1, aq1, 0); break;
+                case 1: TR_FRAG2(qt0, aq0, qt1, aq1, 1); break;
+                case 2: TR_FRAG2(qt0, aq0, qt1, aq1, 2); break;
+                default: TR_FRAG2(qt0, aq0, qt1, aq1, 3); break;
+                }
+                dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf, dkacc[0], 0, 0, 0);
+                dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf, dkacc[1], 0, 0, 0);
             }
         }
     }

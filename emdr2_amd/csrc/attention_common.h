@@ -67,6 +67,31 @@ __device__ __forceinline__ void tr_addresses(uint32_t tile_lds, int lane, uint32
         dst = __builtin_bit_cast(bf16x8, make_uint4(lo_.x, lo_.y, hi_.x, hi_.y));          \
     } while (0)
 
+// Two / four transposed fragments with ONE wait: all reads go out first (they are independent), so their LDS latencies overlap
+#define TR_FRAG2(d0, b0, d1, b1, u)                                                                                  \
+    do {                                                                                                             \
+        uint2 l0_, h0_, l1_, h1_;                                                                                    \
+        TR_READ(l0_, (b0)[0], (u) * 2048); TR_READ(h0_, (b0)[1], (u) * 2048);                                        \
+        TR_READ(l1_, (b1)[0], (u) * 2048); TR_READ(h1_, (b1)[1], (u) * 2048);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(l0_), "+v"(h0_), "+v"(l1_), "+v"(h1_)::"memory");                 \
+        d0 = __builtin_bit_cast(bf16x8, make_uint4(l0_.x, l0_.y, h0_.x, h0_.y));                                     \
+        d1 = __builtin_bit_cast(bf16x8, make_uint4(l1_.x, l1_.y, h1_.x, h1_.y));                                     \
+    } while (0)
+#define TR_FRAG4(d0, b0, d1, b1, d2, b2, d3, b3, u)                                                                  \
+    do {                                                                                                             \
+        uint2 l0_, h0_, l1_, h1_, l2_, h2_, l3_, h3_;                                                                \
+        TR_READ(l0_, (b0)[0], (u) * 2048); TR_READ(h0_, (b0)[1], (u) * 2048);                                        \
+        TR_READ(l1_, (b1)[0], (u) * 2048); TR_READ(h1_, (b1)[1], (u) * 2048);                                        \
+        TR_READ(l2_, (b2)[0], (u) * 2048); TR_READ(h2_, (b2)[1], (u) * 2048);                                        \
+        TR_READ(l3_, (b3)[0], (u) * 2048); TR_READ(h3_, (b3)[1], (u) * 2048);                                        \
+        asm volatile("s_waitcnt lgkmcnt(0)"                                                                          \
+                     : "+v"(l0_), "+v"(h0_), "+v"(l1_), "+v"(h1_), "+v"(l2_), "+v"(h2_), "+v"(l3_), "+v"(h3_)::"memory"); \
+        d0 = __builtin_bit_cast(bf16x8, make_uint4(l0_.x, l0_.y, h0_.x, h0_.y));                                     \
+        d1 = __builtin_bit_cast(bf16x8, make_uint4(l1_.x, l1_.y, h1_.x, h1_.y));                                     \
+        d2 = __builtin_bit_cast(bf16x8, make_uint4(l2_.x, l2_.y, h2_.x, h2_.y));                                     \
+        d3 = __builtin_bit_cast(bf16x8, make_uint4(l3_.x, l3_.y, h3_.x, h3_.y));                                     \
+    } while (0)
+
 // 1-D grid decode shared by the attention kernels: workgroup ids go round-robin to the 8 XCDs (one L2 each); the blocks of one (batch,
 // head) -- which stream the same K/V (or Q/dO) rows -- are given ids 8 apart so they land on the SAME XCD and the shared operand leaves HBM
 // once.  ids: xcd = id & 7, rest = id >> 3, block = rest % nblk, bn = (rest / nblk) * 8 + xcd; returns false for the padded tail.
