@@ -70,3 +70,26 @@ def test_index_refuses_to_run_without_gpu():
     from emdr2_amd.data.emdr2_index import HipIndexShard
     with pytest.raises(_native.NativeError):
         HipIndexShard(768, 100, 0)
+
+
+def test_ops_entry_points_validate_arguments_without_a_gpu(lib):
+    """Bad shapes / null pointers come back as status codes before any launch (no exceptions across the ABI)."""
+    n = ctypes.c_size_t()
+    assert lib.emdr2_mips_exact_workspace_bytes_f32(1000, 4, ctypes.byref(n)) == 0 and n.value >= 8 * 1000 * 4
+    assert lib.emdr2_mips_search_f32(None, 10, 768, 0, None, None, 1, 5, None, None, None, None, None, None, 0, None) == -1
+    assert lib.emdr2_mips_merge_f32(None, None, None, 2, 4, 5, None, None, None, None) == -1
+    one = ctypes.c_void_p(4096)                                          # a non-null, 16-byte aligned fake pointer: shapes are checked first
+    # GEMM: K must be a multiple of 32, split-K only with fp32 output and no epilogue, dropout only unbatched
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 40, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 1, 0.0, 0, None) == -1
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 2, 0.0, 0, None) == -1
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 2, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 1, 0.1, 7, None) == -1
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 2, 0, 1, 0.0, 0, None) == -1
+    assert lib.emdr2_gemm_tn_bf16(one, 64, one, 64, one, 64, 64, 64, 48, 1, None, None) == -1      # R % 32
+    assert lib.emdr2_gemm_tn_bf16(None, 64, one, 64, one, 64, 64, 64, 64, 1, None, None) == -1
+    # attention: head dim 64 and sk % 64 == 0 only (-4 = unsupported shape, the caller falls back to the composed path)
+    args_f = (one, 64, 64, 64, one, 64, 64, 64, one, 64, 64, 64, one, one, one, 1, 1, 32)
+    assert lib.emdr2_attention_fwd(*args_f, 96, 64, 0, 0.125, 0.0, 0, None, None, None) == -4
+    assert lib.emdr2_attention_fwd(*args_f, 128, 32, 0, 0.125, 0.0, 0, None, None, None) == -4
+    assert lib.emdr2_attention_fwd(*args_f, 128, 64, 0, 0.125, 1.5, 0, None, None, None) == -1
+    assert lib.emdr2_dropout(one, one, 64, 12, 0.1, 1, None) == -1          # cols % 8
+    assert lib.emdr2_layernorm_fwd(one, one, one, one, one, one, 4, 12, 1e-5, None) == -1
