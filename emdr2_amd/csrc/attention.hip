@@ -88,6 +88,7 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     // A padded query has every score replaced by -10000: per-lane (scale, offset) = (0, -10000 log2 e) does that without a select.
     const float sc_q = qpad ? 0.f : p.scale * L2E, c_q = qpad ? MASKED2 : 0.f;
     const bool any_qpad = __builtin_amdgcn_ballot_w64(qpad) != 0ull;
+    const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;      // a wave entirely inside the padding of its sequence
     float mrun = -3.0e38f, lrun = 0.f;
     const bool drop = p.drop_p > 0.f;
     const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
@@ -109,8 +110,18 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
             continue;
         const char *sb = smem + stage * 16384;
 
-        // ---- S^T = K Q^T : 2 key sub-blocks x 4 k-steps --------------------------------------------------------------
         floatx16 sacc[2];
+        if (all_qpad) {
+            // Every score of this wave is the mask value -10000: the softmax is uniform over ALL keys.  Same numbers as the general
+            // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[j][r] = 1.f;
+            mrun = MASKED2;
+            lrun += 64.f;
+        } else {
+        // ---- S^T = K Q^T : 2 key sub-blocks x 4 k-steps --------------------------------------------------------------
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -168,6 +179,7 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
                 for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
         }
         mrun = mnew;
+        }
         if (drop) {                                                               // attention dropout after the normaliser (l is un-dropped)
 #pragma unroll
             for (int j = 0; j < 2; ++j)

@@ -76,6 +76,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
         if (qvalid && hi == 0) p.dstat[si] = Dq;
     }
     const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
+    const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;  // a wave of padded queries: every dS is 0
     const float sc = p.scale * L2E;
     const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
 
@@ -115,7 +116,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * 64;
         // every (query of this wave, key of this block) pair masked -> dS == 0: nothing to add
-        if (!wave_live || kmask == 0ull || (p.causal && key0 > q0 + 31)) continue;
+        if (!wave_live || all_qpad || kmask == 0ull || (p.causal && key0 > q0 + 31)) continue;
         const char *sb = smem + stage * 16384;
 
         floatx16 sacc[2], pacc[2];
