@@ -90,6 +90,11 @@ def main():
     sched = AnnealingLR(2e-5, 10, 1000)
     n_params = sum(p.numel() for p in model.parameters())
 
+    sink = None
+    if world > 1:                                                      # bucketed gradient all-reduce overlapped with the backward
+        from emdr2_amd.model import kernels as Kmod
+        from emdr2_amd.training import GradientBuckets
+        sink = Kmod.GRAD_SINK = GradientBuckets(model.parameters())
     indexer = None
     if args.reindex_rows_per_step > 0:
         from emdr2_amd.tasks.openqa.e2eqa.async_indexer import AsyncIndexBuilder
@@ -119,10 +124,15 @@ def main():
             indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
         opt.zero_grad()
+        if sink is not None:
+            sink.begin_step()
         lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
         loss, stats = emdr2_loss(lm, tlp, one, bt["labels"], bt["mask"], eos_id=30523)
         loss.backward()
-        allreduce_gradients(model)
+        if sink is not None:
+            sink.finish()
+        else:
+            allreduce_gradients(model)
         opt.step(lr=sched.step())
         return loss
 

@@ -155,8 +155,15 @@ def w_bf16_perm(p, perm):
     return WEIGHTS.get(p, "perm", lambda: w_bf16(p)[perm].contiguous())
 
 
+GRAD_SINK = None    # a training.GradientBuckets when data-parallel gradient averaging is overlapped with the backward
+
+
 def _accum_grad(p, g_f32):
-    if p.grad is None:
+    """Every parameter gradient of the model is delivered here by the autograd functions of this module (fp32, produced by the
+    weight-gradient GEMMs / reduction kernels)."""
+    if GRAD_SINK is not None and GRAD_SINK.owns(p):
+        GRAD_SINK.accumulate(p, g_f32)
+    elif p.grad is None:
         p.grad = g_f32
     else:
         p.grad += g_f32        # rare (a parameter used twice in one backward): tied embedding / LM head

@@ -38,10 +38,17 @@ def _cross_entropy_forward_step(batch, model, eos_id):
 
 def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler, eos_id, dp_group=None):
     """megatron/training.py:202-230 without the fp16 machinery (bf16 needs no loss scale / overflow skip)."""
+    from emdr2_amd.model import kernels
     optimizer.zero_grad()
+    sink = kernels.GRAD_SINK
+    if sink is not None:
+        sink.begin_step()
     loss, loss_reduced = forward_step_func(data_iterator, model, eos_id)
     loss.backward()
-    allreduce_gradients(model, dp_group)
+    if sink is not None:
+        sink.finish()                                # buckets were all-reduced while the backward ran
+    else:
+        allreduce_gradients(model, dp_group)
     optimizer.step(lr=lr_scheduler.step())
     return loss_reduced
 
@@ -228,6 +235,10 @@ def train(train_valid_datasets_provider, model_provider, forward_step=_cross_ent
     if args.epochs > 0 and end_of_epoch_callback_provider is not None:
         cb1, cb2 = end_of_epoch_callback_provider(args.valid_data), end_of_epoch_callback_provider(args.test_data)
     model, optimizer, lr_scheduler = setup_model_and_optimizer(model_provider)
+    if _dp()[1] > 1:                                                                         # overlap the gradient all-reduce with the backward
+        from emdr2_amd.model import kernels
+        from emdr2_amd.training import GradientBuckets
+        kernels.GRAD_SINK = GradientBuckets(model.parameters())
     if args.iteration == 0 and args.pretrained_checkpoint is not None:                     # train_e2eqa.py:586-593: weights only
         checkpointing.load_checkpoint(args.pretrained_checkpoint, model, None, None)
     print_rank_0('done with setups ...')

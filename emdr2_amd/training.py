@@ -119,3 +119,104 @@ def allreduce_gradients(module, group=None):
         n = g.numel()
         g.copy_(flat[off:off + n].view_as(g))
         off += n
+
+
+class GradientBuckets(object):
+    """Data-parallel gradient averaging, bucketed and overlapped with the backward (the reference does one blocking flattened
+    all-reduce after the backward, megatron/model/distributed.py:35-62).
+
+    Parameters are laid out, in reverse registration order (roughly the order their gradients become final), into flat fp32 buckets;
+    `p.grad` is a view into its bucket, so nothing is copied before or after the collective.  The autograd functions hand every gradient
+    to `accumulate`; once a bucket has received the last expected contribution of each of its parameters it is pre-divided by the world
+    size and all-reduced asynchronously (RCCL over xGMI on the GPU box: the collective runs on the communicator's stream while the
+    backward keeps computing), `finish()` waits for the handles.  How many contributions a parameter receives per step (1, or more for
+    the tied embedding / LM-head weights) is learned in the first step, during which all buckets are reduced in `finish()`.
+    Result = `allreduce_gradients` (tests/test_dist_allreduce.py, gloo, world size 2)."""
+
+    def __init__(self, params, group=None, bucket_bytes=128 << 20):
+        self.group = group
+        self.params = [p for p in params if p.requires_grad][::-1]
+        self.buckets, self.bucket_of, self.view = [], {}, {}
+        cur, cur_n = [], 0
+        for p in self.params:
+            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
+                self._close(cur)
+                cur, cur_n = [], 0
+            cur.append(p); cur_n += p.numel()
+        if cur:
+            self._close(cur)
+        self.expected = None                  # {param: contributions per step}, learned in the first step
+        self.count = {p: 0 for p in self.params}
+        self.launched_early = 0
+        self.begin_step()
+
+    def _close(self, plist):
+        dev = plist[0].device
+        flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
+        b = {"params": plist, "flat": flat, "pending": 0, "handle": None, "launched": False}
+        off = 0
+        for p in plist:
+            self.view[p] = flat[off:off + p.numel()].view(p.shape)
+            self.bucket_of[p] = b
+            off += p.numel()
+        self.buckets.append(b)
+
+    def _world(self):
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            return torch.distributed.get_world_size(self.group)
+        return 1
+
+    def owns(self, p):
+        return p in self.view
+
+    def begin_step(self):
+        """After optimizer.zero_grad(): clear the buckets and the per-step bookkeeping."""
+        for b in self.buckets:
+            b["flat"].zero_()
+            b["handle"], b["launched"] = None, False
+            b["pending"] = sum(1 for p in b["params"] if self.expected and self.expected.get(p, 0) > 0)
+        for p in self.params:
+            self.count[p] = 0
+            p.grad = None
+
+    def accumulate(self, p, g):
+        b = self.bucket_of[p]
+        if b["launched"]:
+            raise RuntimeError("gradient for a parameter whose bucket was already reduced (the contribution pattern changed between steps)")
+        v = self.view[p]
+        if self.count[p] == 0:
+            v.copy_(g.view_as(v))
+            p.grad = v
+        else:
+            v.add_(g.view_as(v))
+        self.count[p] += 1
+        if self.expected is not None:
+            exp = self.expected.get(p, 0)
+            if exp == 0 or self.count[p] > exp:
+                raise RuntimeError("unexpected gradient contribution (the contribution pattern changed between steps)")
+            if self.count[p] == exp:
+                b["pending"] -= 1
+                if b["pending"] == 0:
+                    self._launch(b)
+                    self.launched_early += 1
+
+    def _launch(self, b):
+        b["launched"] = True
+        world = self._world()
+        if world > 1:
+            b["flat"].div_(world)                                          # pre-divide, then sum (distributed.py:56-58)
+            b["handle"] = torch.distributed.all_reduce(b["flat"], group=self.group, async_op=True)
+
+    def finish(self):
+        """After loss.backward(): reduce what is left, wait for everything."""
+        if self.expected is None:
+            self.expected = dict(self.count)
+        elif any(self.count[p] != self.expected.get(p, 0) for p in self.params):
+            raise RuntimeError("gradient contributions differ from the first step")
+        for b in self.buckets:
+            if not b["launched"] and any(self.count[p] for p in b["params"]):
+                self._launch(b)
+        for b in self.buckets:
+            if b["handle"] is not None:
+                b["handle"].wait()
+                b["handle"] = None

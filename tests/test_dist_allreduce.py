@@ -40,3 +40,64 @@ def test_gradients_are_averaged_across_ranks(tmp_path):
             assert b is None
             continue
         assert torch.allclose(a, b) and torch.allclose(a, (r0 + r1) / 2, atol=1e-6)
+
+
+def _bucket_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.training import GradientBuckets
+    torch.manual_seed(0)
+    names = ["emb", "w1", "b1", "w2", "unused", "w3"]
+    shapes = [(50, 16), (64, 16), (64,), (16, 64), (3, 16), (300, 300)]
+    params = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+    sink = GradientBuckets(params, bucket_bytes=64 * 16 * 4 + 300)          # small buckets: several of them, one holding a single big param
+    K.GRAD_SINK = sink
+    assert len(sink.buckets) >= 3 and sum(b["flat"].numel() for b in sink.buckets) == sum(p.numel() for p in params)
+    record = []
+    for step in range(3):
+        g = torch.Generator().manual_seed(1000 * step + rank)
+        sink.begin_step()
+        assert all(p.grad is None for p in params)
+        contrib = {}
+        # "backward": w3, w2, b1, w1, then the tied embedding twice (decoder side first, encoder side last); `unused` never gets a gradient
+        for i in (5, 3, 2, 1, 0, 0):
+            gi = torch.randn(shapes[i], generator=g)
+            contrib[i] = contrib.get(i, 0) + gi
+            K._accum_grad(params[i], gi)
+        early = sink.launched_early
+        sink.finish()
+        record.append(([None if p.grad is None else p.grad.clone() for p in params], [contrib.get(i) for i in range(len(params))], early))
+        assert params[4].grad is None                                       # stays out of the optimizer step, like the unbucketed path
+    torch.save(record, os.path.join(out_dir, "b%d.pt" % rank))
+    # a changed contribution pattern must fail loudly, not average garbage
+    sink.begin_step()
+    K._accum_grad(params[5], torch.zeros(shapes[5]))
+    try:
+        K._accum_grad(params[5], torch.zeros(shapes[5]))
+        ok = False
+    except RuntimeError:
+        ok = True
+    assert ok
+    K.GRAD_SINK = None
+    dist.destroy_process_group()
+
+
+def test_bucketed_overlapped_gradient_averaging_matches_plain_average(tmp_path):
+    """GradientBuckets: p.grad views into flat buckets, buckets reduced as soon as their last expected contribution arrives (from the
+    second step on), tied parameters with two contributions, parameters without gradients, loud failure on pattern changes."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bucket_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = torch.load(os.path.join(str(tmp_path), "b0.pt")), torch.load(os.path.join(str(tmp_path), "b1.pt"))
+    for step in range(3):
+        g0, c0, early0 = r0[step]
+        g1, c1, early1 = r1[step]
+        for a, b, x, y in zip(g0, g1, c0, c1):
+            if x is None:
+                assert a is None and b is None
+                continue
+            assert torch.allclose(a, b) and torch.allclose(a, (x + y) / 2, atol=1e-6)
+        if step == 0:
+            assert early0 == 0 and early1 == 0                               # the first step learns the contribution counts
+    assert r0[2][2] > r0[1][2] > 0                                           # later steps launch buckets from inside the "backward"
