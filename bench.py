@@ -96,10 +96,13 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
+    if os.environ.get("EMDR2_SINGLE_DEVICE"):          # dry run of the N-rank code path on a 1-GPU box: all ranks share cuda:0 (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
     from emdr2_amd import _native
     from emdr2_amd.data.emdr2_index import HipIndexShard, merge_shard_results, shard_bounds

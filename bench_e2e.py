@@ -54,10 +54,13 @@ def main():
                          "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
     args = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("EMDR2_SINGLE_DEVICE"):          # dry run of the N-rank code path on a 1-GPU box: all ranks share cuda:0 (use with gloo)
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.distributed.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
     from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, shard_bounds
     from emdr2_amd.data.evidence_arena import EvidenceArena
@@ -165,7 +168,7 @@ def main():
             "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                    % (B, K, S_ret, S, L, args.rows, args.layers),
                        "global_batch": B * world, "params": n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
-                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss),
+                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss.detach()),
                        "reindex_rows_per_step": args.reindex_rows_per_step,
                        "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
             "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
