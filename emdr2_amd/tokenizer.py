@@ -123,7 +123,8 @@ class FullTokenizer(object):
         return [self.vocab[t] for t in tokens]
 
     def convert_ids_to_tokens(self, ids):
-        return [self.inv_vocab[int(i)] for i in ids]
+        # ids in the padded tail of the embedding table (vocab_size_with_padding) have no token: an untrained reader can emit them
+        return [self.inv_vocab.get(int(i), "[UNK]") for i in ids]
 
     @staticmethod
     def convert_tokens_to_string(tokens, clean_up_tokenization_spaces=True):

@@ -65,3 +65,10 @@ def test_answer_presence_validation_matches_the_reference():
     docs = {int(k): tuple(v) for k, v in ref["docs"].items()}
     stats = calculate_matches(docs, [q[0] for q in ref["questions"]], [(q[1], q[2]) for q in ref["questions"]], match_type="string")
     assert list(stats.top_k_hits) == ref["top_k_hits"] and [list(h) for h in stats.questions_doc_hits] == ref["questions_doc_hits"]
+
+
+def test_decode_maps_ids_of_the_padded_vocabulary_tail_to_unk():
+    from emdr2_amd.tokenizer import BertWordPieceTokenizer
+    t = BertWordPieceTokenizer(os.path.join(GOLD, "tokenizer_vocab.txt"), vocab_extra_ids=100)
+    ids = t.tokenize("the capital of france")
+    assert t.decode(ids + [t.vocab_size + 5]) == "the capital of france [UNK]"
