@@ -590,15 +590,33 @@ __global__ void __launch_bounds__(256) lse_gather_bwd_kernel(const uint16_t *log
 }
 
 // ---- optimizer: fp32 masters, decoupled weight decay Adam (apex FusedAdam defaults, training.py:89; SURVEY 8c: unpinned) -------
-__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, long long n, float *out)
+// Deterministic: block partials go to scratch[0 .. grid) and the LAST block to finish adds them up in index order, so the sum (and with
+// it the clip factor every data-parallel replica derives from it) does not depend on the arrival order of atomics.  scratch: 1024
+// partial slots + one counter word at [1024] (zero before the first use; the kernel resets it).
+__global__ void __launch_bounds__(256) sumsq_kernel(const float *g, long long n, float *out, float *scratch)
 {
     __shared__ float red[4];
+    __shared__ bool last;
     float s = 0.f;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) s += g[i] * g[i];
     s = wave_sum(s);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, red[0] + red[1] + red[2] + red[3]);
+    unsigned *counter = (unsigned *)(scratch + 1024);                  // fixed slot: partials of launches with other grid sizes never alias it
+    if (threadIdx.x == 0) {
+        scratch[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+        __threadfence();
+        last = atomicAdd(counter, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    __threadfence();
+    float t = 0.f;
+    for (unsigned i = threadIdx.x; i < gridDim.x; i += 256) t += ((volatile float *)scratch)[i];   // fixed assignment of partials to lanes
+    t = wave_sum(t);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) { *out += (red[0] + red[1]) + (red[2] + red[3]); *counter = 0u; }    // launches on one stream are ordered
 }
 
 __global__ void __launch_bounds__(256) adam_kernel(float *master, const float *grad, float *m, float *v, uint16_t *param_bf16, long long n, float lr,
@@ -779,12 +797,12 @@ extern "C" int emdr2_lse_gather_bwd(const void *logits, const int64_t *labels, c
     return LAUNCH_OK();
 }
 
-extern "C" int emdr2_sumsq_f32(const float *g, int64_t n, float *out, void *stream)
+extern "C" int emdr2_sumsq_f32(const float *g, int64_t n, float *out, float *scratch, void *stream)
 {
-    if (!g || !out || n < 1) return -1;
-    int blocks = (int)((n + 255) / 256);
-    if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long long)n, out);
+    if (!g || !out || !scratch || n < 1) return -1;
+    int blocks = (int)((n + 2047) / 2048);                               // a function of n only: every replica uses the same grid
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, g, (long long)n, out, scratch);
     return LAUNCH_OK();
 }
 

@@ -82,8 +82,10 @@ class FusedAdam(object):
         if not params:
             return 0.0
         gsq = torch.zeros(1, dtype=torch.float32, device=params[0].device)
+        if getattr(self, "_scratch", None) is None:
+            self._scratch = torch.zeros(1025, dtype=torch.float32, device=params[0].device)
         for p in params:
-            _native.check(lib.emdr2_sumsq_f32(p.grad.data_ptr(), p.grad.numel(), gsq.data_ptr(), sp), "sumsq")
+            _native.check(lib.emdr2_sumsq_f32(p.grad.data_ptr(), p.grad.numel(), gsq.data_ptr(), self._scratch.data_ptr(), sp), "sumsq")
         for g in self.groups:
             for p in g["params"]:
                 if p.grad is None:

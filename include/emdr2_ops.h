@@ -108,7 +108,9 @@ int emdr2_lse_gather_bwd(const void *logits, const int64_t *labels, const float 
 
 /* Optimizer step on fp32 masters (FP16_Optimizer + apex FusedAdam, training.py:89-93, fp16/fp16.py:420-474): global-norm clip
  * (mpu/grads.py:74-127) folded in through gnorm_sq; decoupled weight decay; writes the bf16 working copy. */
-int emdr2_sumsq_f32(const float *g, int64_t n, float *out, void *stream);
+/* *out += sum g[i]^2, deterministically (block partials summed in index order by the last block): data-parallel replicas derive
+ * bit-identical clip factors.  scratch: 1025 floats, zero-initialised once by the caller (1024 partials + a counter the kernel resets). */
+int emdr2_sumsq_f32(const float *g, int64_t n, float *out, float *scratch, void *stream);
 int emdr2_adam_step(float *master, const float *grad, float *m, float *v, void *param_bf16, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream);
 int emdr2_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
