@@ -60,7 +60,7 @@ SIGNATURES.update({
     "emdr2_softmax_mask_t": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _u32, _vp]),
     "emdr2_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
     "emdr2_embedding_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
-    "emdr2_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "emdr2_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u32, _vp]),
     "emdr2_attention_fwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                    _f32, _f32, _u32, _vp, _vp, _vp]),
     "emdr2_attention_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,

@@ -514,18 +514,49 @@ __global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids
     }
 }
 
+// word-embedding rows: atomic scatter (ids are spread over the vocabulary, little contention)
 __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids, const long long *types, const uint16_t *dout, float *dW, float *dP,
                                                             float *dT, long long tokens, int S, int H, float drop_p, uint32_t seed)
 {
     const long long t = blockIdx.x;
-    const long long id = ids[t], pos = t % S;
-    const long long ty = types ? types[t] : 0;
+    const long long id = ids[t];
+    const uint32_t rh = emdr2_row_hash(seed, (unsigned long long)t), thr = emdr2_drop_thr(drop_p);
+    const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
     for (int i = threadIdx.x; i < H; i += 256) {
         float g = bf2f(dout[t * H + i]);
-        if (drop_p > 0.f) g = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)t), (uint32_t)i, emdr2_drop_thr(drop_p)) ? g * emdr2_keep_scale(drop_p) : 0.f;
+        if (drop_p > 0.f) g = emdr2_keep(rh, (uint32_t)i, thr) ? g * ik : 0.f;
         atomicAdd(&dW[id * H + i], g);
-        atomicAdd(&dP[pos * H + i], g);
-        if (types) atomicAdd(&dT[ty * H + i], g);
+    }
+}
+
+// position and token-type rows: every sequence hits the same S position rows and the same one or two type rows, so an atomic per token
+// serialises thousands of adds on a few addresses.  One thread owns (position, column), walks the batch, and writes the position sum
+// with a plain add; the type sums (<= 4 types) are kept in registers and cost one atomic per (position, column) instead of one per token.
+__global__ void __launch_bounds__(256) embedding_bwd_pos_kernel(const long long *types, const uint16_t *dout, float *dP, float *dT, long long tokens,
+                                                                int S, int H, int n_types, float drop_p, uint32_t seed)
+{
+    const int pos = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
+    if (i >= H) return;
+    const long long nb = tokens / S;
+    const uint32_t thr = emdr2_drop_thr(drop_p);
+    const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
+    float ap = 0.f, at[4] = {0.f, 0.f, 0.f, 0.f};
+    for (long long b = 0; b < nb; ++b) {
+        const long long t = b * S + pos;
+        float g = bf2f(dout[t * H + i]);
+        if (drop_p > 0.f) g = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)t), (uint32_t)i, thr) ? g * ik : 0.f;
+        ap += g;
+        if (types) {
+            const int ty = (int)types[t];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) at[k] += (ty == k) ? g : 0.f;
+        }
+    }
+    dP[(long long)pos * H + i] += ap;
+    if (types) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < n_types && at[k] != 0.f) atomicAdd(&dT[(long long)k * H + i], at[k]);
     }
 }
 
@@ -764,11 +795,14 @@ extern "C" int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, con
 }
 
 extern "C" int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S,
-                                   int H, float drop_p, uint32_t seed, void *stream)
+                                   int H, int n_types, float drop_p, uint32_t seed, void *stream)
 {
     if (!ids || !dout || !dW || !dP || tokens < 1 || S < 1 || H < 1 || (types && !dT) || drop_p < 0.f || drop_p >= 1.f) return -1;
+    if (tokens % S || (types && (n_types < 1 || n_types > 4))) return -4;
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
                        (const uint16_t *)dout, dW, dP, dT, (long long)tokens, S, H, drop_p, seed);
+    hipLaunchKernelGGL(embedding_bwd_pos_kernel, dim3((unsigned)S, (unsigned)((H + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)types, (const uint16_t *)dout, dP, dT, (long long)tokens, S, H, n_types, drop_p, seed);
     return LAUNCH_OK();
 }
 

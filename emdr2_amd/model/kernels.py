@@ -497,7 +497,7 @@ class EmbeddingFn(torch.autograd.Function):
         dW, dP = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(P, dtype=torch.float32)
         dT = torch.zeros_like(T, dtype=torch.float32) if types is not None else None
         _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
-                                                 float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
+                                                 T.shape[0] if dT is not None else 0, float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
         _accum_grad(W, dW)
         _accum_grad(P, dP)
         if dT is not None:

@@ -95,11 +95,12 @@ int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
 int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int64_t n, void *stream);
 
 /* Embedding.forward (language_model.py:169-181): out[t] = dropout(W[ids[t]] + P[t % S] (+ T[types[t]])); bwd scatter-adds the (masked)
- * gradient into fp32 grads.  Dropout element = (row t, column i). */
+ * gradient into fp32 grads (word rows: atomics; position rows: one owner thread per (position, column), no atomics; the <= 4 type rows:
+ * register partials, one atomic per (position, column)).  tokens % S == 0.  Dropout element = (row t, column i). */
 int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, const void *W, const void *P, const void *T, void *out, int64_t tokens, int S,
                         int H, float drop_p, uint32_t seed, void *stream);
 int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, const void *dout, float *dW, float *dP, float *dT, int64_t tokens, int S, int H,
-                        float drop_p, uint32_t seed, void *stream);
+                        int n_types, float drop_p, uint32_t seed, void *stream);
 
 /* log-softmax over the vocabulary + gather of the gold token (train_e2eqa.py:79-96,152-160): gold[row] = logits[row, label] - lse */
 int emdr2_lse_gather_fwd(const void *logits, const int64_t *labels, float *gold, float *lse, int64_t rows, int V, void *stream);

@@ -356,3 +356,24 @@ def test_attention_random_shapes_property():
         causal = bool(sq == sk and rng.integers(0, 2))
         drop = float(rng.choice([0.0, 0.1]))
         _attention_case(b, heads, sq, sk, causal, drop, 1000 + case, 50 + case)
+
+
+def test_embedding_backward_with_token_types_and_positions():
+    """Word rows by atomic scatter, position rows by owner threads, type rows by register partials: all three against torch."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(21)
+    b, s, H, V = 37, 48, 96, 200
+    Wt = torch.nn.Parameter(torch.randn((V, H), generator=g, device="cuda")); Pt = torch.nn.Parameter(torch.randn((64, H), generator=g, device="cuda"))
+    Tt = torch.nn.Parameter(torch.randn((2, H), generator=g, device="cuda"))
+    ids = torch.randint(0, V, (b, s), generator=g, device="cuda"); types = torch.randint(0, 2, (b, s), generator=g, device="cuda")
+    out = K.embedding(ids, types, Wt, Pt, Tt)
+    w = torch.randn(out.shape, generator=g, device="cuda")
+    (out.float() * w).sum().backward()
+    f = lambda p: p.detach().bfloat16().float().requires_grad_(True)
+    Wf, Pf, Tf = f(Wt), f(Pt), f(Tt)
+    ref = Wf[ids] + Pf[None, :s] + Tf[types]
+    (ref * w.bfloat16().float()).sum().backward()
+    rel = lambda a, r: float((a.detach().float() - r.detach()).abs().max() / (r.detach().abs().max() + 1e-6))
+    assert rel(out, ref) < 1e-2
+    assert rel(Wt.grad, Wf.grad) < 1e-2 and rel(Pt.grad, Pf.grad) < 1e-2 and rel(Tt.grad, Tf.grad) < 1e-2
+    assert float(Pt.grad[s:].abs().max()) == 0.0                          # rows beyond the sequence length untouched
