@@ -13,14 +13,13 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
-#include "rng.h"
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef float floatx16 __attribute__((ext_vector_type(16)));
-typedef __attribute__((address_space(1))) const void gptr_t;
-typedef __attribute__((address_space(3))) void lptr_t;
+#include "gemm_common.h"
 
 #define GNST 3
+
+int emdr2_gemm8_try(const void *A, int64_t lda, const void *B, int64_t ldb, void *C, int64_t ldc, int M, int N, int K, float alpha,
+                    const float *bias, int gelu, void *pre_act, const void *residual, int residual_mode, float drop_p, uint32_t seed,
+                    hipStream_t stream);   // gemm8.hip
 
 struct GemmParams {
     const char *A, *B;
@@ -35,58 +34,11 @@ struct GemmParams {
     int gelu, out_f32;
     float drop_p;             // dropout on (acc*alpha + bias [gelu]) before the residual add: bias_dropout_add (transformer.py:397-413)
     uint32_t seed;            // keep bit = emdr2_keep(row_hash(seed, m), n, thr)
-    int ablate;               // timing experiments (EMDR2_GEMM_ABLATE): 1 = no epilogue, 2 = no k-loop, 3 = epilogue without global stores
+    int ablate;               // -DEMDR2_EXPERIMENTS builds only (EMDR2_GEMM_ABLATE): 1 = no epilogue, 2 = no k-loop, 3 = epilogue without global stores
     int ngroup;               // n-tiles per L2-resident group of B panels (order >= 1)
     int tiles_m, tiles_n, order; // order 1: 1-D grid, n-tiles fastest inside a per-XCD contiguous tile range (operand A read once from HBM)
     int splitk;               // > 1: blockIdx.z also enumerates K slices; fp32 output accumulated with atomics (C pre-zeroed)
 };
-
-__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
-__device__ __forceinline__ uint16_t f32_to_bf16(float f)
-{
-    uint32_t u = __float_as_uint(f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40); // quiet NaN
-    u += 0x7fffu + ((u >> 16) & 1u);                                             // round to nearest even
-    return (uint16_t)(u >> 16);
-}
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float floatx2_t __attribute__((ext_vector_type(2)));
-// two fp32 -> packed bf16 pair with the hardware converter (v_cvt_pk_bf16_f32, round to nearest even, NaN preserved)
-__device__ __forceinline__ uint32_t pack2_bf16(float a, float b)
-{
-    const floatx2_t v = {a, b};
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
-}
-// erf-form GELU 0.5 x (1 + erf(x / sqrt 2)) (transformer.py:80,103-104: F.gelu, not the tanh fusion).  erf by Abramowitz-Stegun 7.1.26
-// (|error| <= 1.5e-7, far below the bf16 output grid) on one v_rcp and one v_exp: ~14 VALU ops where the library erff cost ~3x that and
-// made the FFN1 epilogue as long as a third of its k-loop.
-// outputs are written once and not re-read by this kernel: streaming stores keep them from evicting the A panels the other n-tiles of
-// the XCD are about to reuse (EMDR2_GEMM_NT=0 switches back to plain stores for A/B runs)
-typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void store_stream(uint16_t *dst, uint4 v)
-{
-    const u32x4_t x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, (u32x4_t *)dst);
-}
-// d/dx of the erf-form GELU: Phi(x) + x phi(x), same erf approximation and the same exponential as the forward
-__device__ __forceinline__ float gelu_erf_grad(float x)
-{
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);          // exp(-x^2 / 2)
-    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-poly, e, 1.0f), x));
-    return fmaf(x * 0.3989422804014327f, e, cdf);
-}
-__device__ __forceinline__ float gelu_erf(float x)
-{
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
-}
 
 // VEC: bf16 output staged through LDS per wave and written as 16-byte row segments (bias / GELU / pre-activation / residual
 // applied on 8-element vectors); otherwise (fp32 output, split-K atomics, unaligned leading dimensions) the scalar epilogue.
@@ -158,7 +110,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     const int c_begin = zs * per;
     const int nch = (c_begin + per <= nch_all ? per : (nch_all > c_begin ? nch_all - c_begin : 0));
     if (nch == 0) return;
+#ifdef EMDR2_EXPERIMENTS
     const int nch_run = p.ablate == 2 ? 0 : nch;
+#else
+    const int nch_run = nch;
+#endif
     int pf_c = 0, pf_stage = 0;
     auto issue = [&]() {
         const int c = c_begin + (pf_c < nch ? pf_c : nch - 1);      // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
@@ -210,7 +166,9 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two speculative chunks
 
+#ifdef EMDR2_EXPERIMENTS
     if (p.ablate == 1) { if (acc[0][0][0] == 123.456f) ((float *)p.C)[0] = acc[1][3][5]; return; }
+#endif
     if (VEC) {
         // ---- vector epilogue: acc -> LDS (fp32, wave-private 32 x 128 half tile, pitch 132) -> 8-wide row segments ----------
         __syncthreads();                                           // every wave is done with the operand ring
@@ -287,7 +245,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     uint32_t w[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
-                    if (p.ablate != 3 || w[0] == 0x12345678u) store_stream((uint16_t *)p.C + o, make_uint4(w[0], w[1], w[2], w[3]));
+#ifdef EMDR2_EXPERIMENTS
+                    if (p.ablate != 3 || w[0] == 0x12345678u)
+#endif
+                    store_stream((uint16_t *)p.C + o, make_uint4(w[0], w[1], w[2], w[3]));
                 }
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this half are done before the next half overwrites
@@ -336,12 +297,16 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
     }
     GemmParams q = p;
     q.tiles_m = (p.M + BM - 1) / BM; q.tiles_n = (p.N + BN - 1) / BN;
+#ifdef EMDR2_EXPERIMENTS
     static const int order_env = getenv("EMDR2_GEMM_ORDER") ? atoi(getenv("EMDR2_GEMM_ORDER")) : 1;
     static const int ablate_env = getenv("EMDR2_GEMM_ABLATE") ? atoi(getenv("EMDR2_GEMM_ABLATE")) : 0;
+    static const int l2_env = getenv("EMDR2_GEMM_L2_KB") ? atoi(getenv("EMDR2_GEMM_L2_KB")) : 2560;
+#else
+    constexpr int order_env = 1, ablate_env = 0, l2_env = 2560;
+#endif
     q.ablate = ablate_env;
     q.order = (order_env >= 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
     // B panels of BN x K bf16 that fit about half of a 4 MB L2 (the rest holds the A panels in flight and the output lines in transit)
-    static const int l2_env = getenv("EMDR2_GEMM_L2_KB") ? atoi(getenv("EMDR2_GEMM_L2_KB")) : 2560;
     const long long panel = (long long)BN * p.K * 2;
     int ng = (int)((long long)l2_env * 1024 / (panel > 0 ? panel : 1));
     if (ng < 1) ng = 1;
@@ -383,8 +348,20 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
     p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k; p.drop_p = drop_p; p.seed = seed;
     const int batch = batch1 * batch2;
+    if (batch == 1 && split_k == 1 && !out_f32) {
+        // large unbatched linears: the persistent 256 x 256 x 64 kernel (gemm8.hip); -4 = shape not covered there
+#ifdef EMDR2_EXPERIMENTS
+        static const int g8_env = getenv("EMDR2_GEMM8") ? atoi(getenv("EMDR2_GEMM8")) : 1;
+        if (g8_env)
+#endif
+        {
+            const int rc = emdr2_gemm8_try(A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, gelu, pre_act, residual, residual_mode, drop_p, seed, (hipStream_t)stream);
+            if (rc != -4) return rc;
+        }
+    }
     if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
     if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);
+#ifdef EMDR2_EXPERIMENTS
     static const int tile_env = getenv("EMDR2_GEMM_TILE") ? atoi(getenv("EMDR2_GEMM_TILE")) : 42;
     // EMDR2_GEMM_TILE=22: 128 x 256 tiles on 4 waves, two workgroups per CU (one's epilogue overlaps the other's MFMA loop).  Measured
     // 5-8 % SLOWER than 256 x 256 on the step's linears (1.5x the L2->LDS operand traffic per flop), kept for experiments only.
@@ -392,5 +369,6 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     // EMDR2_GEMM_TILE=44: 256 x 256 tile on FOUR waves of 128 x 128 (256 accumulator registers per lane, one wave per SIMD): 8 fragment
     // reads per 16 MFMAs instead of 6 per 8 -> a third less LDS read traffic per flop
     if (tile_env == 44 && split_k == 1) return launch_gemm<2, 2, 4>(p, batch, (hipStream_t)stream);
+#endif
     return launch_gemm<4, 2>(p, batch, (hipStream_t)stream);
 }
