@@ -92,12 +92,16 @@ def _invalidate_weight_caches():
     kernels.WEIGHTS.invalidate()
 
 
-def save_checkpoint(save_dir, iteration, model, optimizer=None, lr_scheduler=None, rank=0, barrier=None):
+def save_checkpoint(save_dir, iteration, model, optimizer=None, lr_scheduler=None, rank=0, barrier=None, args=None):
     """checkpointing.py:94-135: data-parallel rank 0 writes, then the tracker is updated."""
     if rank == 0:
         name = get_checkpoint_name(save_dir, iteration)
         os.makedirs(os.path.dirname(name), exist_ok=True)
-        state = {'iteration': iteration, 'model': emdr2_state_dict(model)}
+        # checkpoint_version 1.0 = the QKV / KV projections are stored in the [np, hn, 3] / [np, hn, 2] interleaved row order
+        # (transformer.py:225-259); without the key the reference assumes version 0 and re-orders the rows on load (checkpointing.py:236).
+        state = {'checkpoint_version': 1.0, 'iteration': iteration, 'model': emdr2_state_dict(model)}
+        if args is not None:
+            state['args'] = args
         if optimizer is not None:
             state['optimizer'] = optimizer.state_dict()
         if lr_scheduler is not None:
@@ -123,24 +127,43 @@ def read_tracker(load_dir):
     return int(s), False
 
 
-def _read(load_dir):
+def _read(load_dir, want_release=False):
     iteration, release = read_tracker(load_dir)
     if iteration == 0 and not release:
-        return None, 0
-    return torch.load(get_checkpoint_name(load_dir, iteration, release), map_location='cpu', weights_only=False), iteration
+        return (None, 0, False) if want_release else (None, 0)
+    state = torch.load(get_checkpoint_name(load_dir, iteration, release), map_location='cpu', weights_only=False)
+    _check_version(state)
+    return (state, iteration, release) if want_release else (state, iteration)
+
+
+def _check_version(state):
+    """The modules here read the version-1.0 row order only.  Version 0 files (no 'checkpoint_version' key written by an old Megatron:
+    rows grouped [3, np, hn]) would load silently with scrambled Q/K/V rows; the reference converts them on the fly
+    (transformer.py:225-248), this loader refuses them."""
+    version = state.get('checkpoint_version', 0)
+    if version < 1.0:
+        raise ValueError("checkpoint_version %s: the QKV rows of this file are not in the [np, hn, 3] order this loader reads; "
+                         "re-save it with the reference (which converts version 0 on load) first" % version)
 
 
 def load_checkpoint(load_dir, model, optimizer=None, lr_scheduler=None):
     """Resume (checkpointing.py:138-263); returns the iteration (0 = nothing to load)."""
-    state, iteration = _read(load_dir)
+    state, iteration, release = _read(load_dir, want_release=True)
     if state is None:
         return 0
     load_emdr2_state_dict(model, state['model'])
-    if optimizer is not None and 'optimizer' in state:
-        optimizer.load_state_dict(state['optimizer'])
-    if lr_scheduler is not None and 'lr_scheduler' in state:
-        lr_scheduler.load_state_dict(state['lr_scheduler'])
     _invalidate_weight_caches()
+    if release:
+        # a released checkpoint starts a NEW run: iteration 0, fresh optimizer and schedule (checkpointing.py:196-204,243-256)
+        return 0
+    if optimizer is not None and 'optimizer' in state:
+        try:
+            optimizer.load_state_dict(state['optimizer'])
+        except (KeyError, TypeError, AttributeError) as exc:
+            raise ValueError("the optimizer state of this checkpoint is not in this package's format (a reference FP16_Optimizer state?): "
+                             "load the weights only with --no-load-optim (%r)" % (exc,))
+        if lr_scheduler is not None and 'lr_scheduler' in state:      # the reference loads the schedule only together with the optimizer
+            lr_scheduler.load_state_dict(state['lr_scheduler'])
     return state.get('iteration', iteration)
 
 

@@ -141,8 +141,15 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
             acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV[ks], av[f][ks], acc[2 * (MH) + f][NH], 0, 0, 0)
-#define G8_SYNC_COMPUTE(MFMAS)                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                                      \
+#define G8_SYNC_COMPUTE(MFMAS) G8_SYNC_COMPUTE_W(asm volatile("s_waitcnt vmcnt(8)" ::: "memory"), MFMAS)
+// first K-tile after a tile seam: the epilogue's stores sit in the (in-order) vmcnt queue between the DMA issued before the seam and the
+// DMA issued now.  "All DMA except the newest four half-tiles has landed" is then vmcnt(8 + stores): the write-backs of the previous
+// tile drain behind the next tile's MFMAs instead of stalling its first phase.
+#define G8_SYNC_COMPUTE_SEAM(MFMAS)                                                                                                       \
+    G8_SYNC_COMPUTE_W(if (after_seam) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + EPI_STORES) : "memory");                               \
+                      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory"), MFMAS)
+#define G8_SYNC_COMPUTE_W(WAIT, MFMAS)                                                                                                    \
+    WAIT;                                                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
     __builtin_amdgcn_s_barrier();                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
@@ -168,26 +175,29 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     G8_BARRIER();
     if (wr == 1) { G8_BARRIER(); }
 
+    // stores one wave issues per tile (LSE mode: data-dependent count, no relaxation)
+    constexpr int EPI_STORES = (EPI & G8_LSE) ? 0 : ((EPI & G8_PRE) ? 32 : 16);
     for (int ti = 0; ti < my_count; ++ti) {
         for (int kt2 = 0; kt2 < KT; kt2 += 2) {
+            const bool after_seam = EPI_STORES > 0 && kt2 == 0 && ti > 0;
             // ---- K-tile in buffer 0
             G8_READ_B(0, 0, b0v); G8_READ_A(0, 0);
             __builtin_amdgcn_sched_barrier(0);
             G8_STAGE(2, 1);
-            G8_SYNC_COMPUTE(G8_MFMA(0, 0, b0v));
+            G8_SYNC_COMPUTE_SEAM(G8_MFMA(0, 0, b0v));
             G8_BARRIER();
             G8_READ_B(0, 1, b1v);
             __builtin_amdgcn_sched_barrier(0);
             G8_STAGE(3, 1);
-            G8_SYNC_COMPUTE(G8_MFMA(0, 1, b1v));
+            G8_SYNC_COMPUTE_SEAM(G8_MFMA(0, 1, b1v));
             G8_BARRIER();
             G8_READ_A(0, 1);
             __builtin_amdgcn_sched_barrier(0);
             G8_STAGE(0, 0);
-            G8_SYNC_COMPUTE(G8_MFMA(1, 1, b1v));
+            G8_SYNC_COMPUTE_SEAM(G8_MFMA(1, 1, b1v));
             G8_BARRIER();
             G8_STAGE(1, 0);
-            G8_SYNC_COMPUTE(G8_MFMA(1, 0, b0v));
+            G8_SYNC_COMPUTE_SEAM(G8_MFMA(1, 0, b0v));
             G8_BARRIER();
             // ---- K-tile in buffer 1
             G8_READ_B(1, 0, b0v); G8_READ_A(1, 0);
@@ -228,19 +238,22 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
             const float keep_scale = emdr2_keep_scale(p.drop_p);
             const uint32_t thr = emdr2_drop_thr(p.drop_p);
             constexpr int npass = (EPI & G8_PRE) ? 2 : 1;         // with a pre-activation output: one pass for it, one for the activation
+            // residual block of this wave in row order: all sixteen 16-byte loads go out before any math (the operand registers of the main
+            // loop are free now), so one HBM latency is exposed per tile instead of one per 32-row slab
+            uint4 rr[4][4];
+            if constexpr (HAS_RES) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
-                // residual rows of this slab in row order: all four 16-byte loads go out before the math and the LDS round trip
-                uint4 rr[4];
-                if constexpr (HAS_RES) {
+                for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const u32x4_t t = __builtin_nontemporal_load(
                             (const u32x4_t *)((const uint16_t *)p.R + (long long)(m_w + mi * 32 + ps * 8 + prow) * p.ldc + n_w + pc16 * 8));
-                        rr[ps] = make_uint4(t.x, t.y, t.z, t.w);
+                        rr[mi][ps] = make_uint4(t.x, t.y, t.z, t.w);
                     }
-                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
 #pragma unroll
                 for (int pass = 0; pass < npass; ++pass) {
                     const bool final_pass = pass == npass - 1;
@@ -287,7 +300,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                         const uint2 hi2 = *(const uint2 *)(stg + row * 128 + (((2 * pc16 + 1) ^ (row & 15)) << 3));
                         uint32_t w[4] = {lo.x, lo.y, hi2.x, hi2.y};
                         if (HAS_RES && final_pass) {
-                            const uint32_t rw[4] = {rr[ps].x, rr[ps].y, rr[ps].z, rr[ps].w};
+                            const uint32_t rw[4] = {rr[mi][ps].x, rr[mi][ps].y, rr[mi][ps].z, rr[mi][ps].w};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float x0 = bf16_to_f32((uint16_t)(w[q] & 0xffff)), x1 = bf16_to_f32((uint16_t)(w[q] >> 16));

@@ -243,7 +243,7 @@ class MLPFn(torch.autograd.Function):
     running a separate 3 x [tokens, ffn] elementwise pass between two autograd nodes."""
 
     @staticmethod
-    def forward(ctx, x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
+    def forward(ctx, x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0, grad_on=True):
         _check_bf16(x, residual)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -253,7 +253,9 @@ class MLPFn(torch.autograd.Function):
         F = w1.shape[0]
         # the pre-activation is only needed by a backward that will really run from THIS forward: not in no-grad passes (the one-context
         # pass, evaluation) and not in the first run of a checkpointed layer, whose saved tensors are dropped and rebuilt by the re-run
-        need_pre = any(ctx.needs_input_grad) and ATTN_STASH.mode != 'store'
+        # (`grad_on` is the caller's grad mode: inside Function.forward grad is always off, and needs_input_grad reflects requires_grad of
+        # the parameters even under torch.no_grad())
+        need_pre = grad_on and any(ctx.needs_input_grad) and ATTN_STASH.mode != 'store'
         pre = torch.empty((M, F), dtype=BF16, device=x.device) if need_pre else None
         inter = torch.empty((M, F), dtype=BF16, device=x.device)
         gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
@@ -293,11 +295,11 @@ class MLPFn(torch.autograd.Function):
         db1 = torch.zeros(F, dtype=torch.float32, device=dy.device)
         _accum_grad(w1, weight_grad_tn(dpre, x2, colsum=db1))
         _accum_grad(b1, db1)
-        return dx, None, None, None, None, dres, None, None
+        return dx, None, None, None, None, dres, None, None, None
 
 
 def mlp(x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
-    return MLPFn.apply(x, w1, b1, w2, b2, residual, drop_p, seed)
+    return MLPFn.apply(x, w1, b1, w2, b2, residual, drop_p, seed, torch.is_grad_enabled())
 
 
 class LayerNormFn(torch.autograd.Function):

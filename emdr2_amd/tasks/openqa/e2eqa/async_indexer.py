@@ -79,14 +79,14 @@ class AsyncIndexBuilder(IndexBuilder):
     def maybe_swap(self, iteration, force=False):
         """At a step boundary: if the pass is complete (on every rank) and the reload interval has gone by, swap in the new image and
         start the next pass.  Returns True when the index was updated."""
+        # Only rank-uniform conditions may return before the collective below: `iteration`, `force` and the interval are the same on every
+        # rank, the state of this rank's pass is not (the last shard is shorter, so ranks finish their passes on different steps).
         if not force and iteration < self.last_reload_iteration + self.index_reload_interval:
             return False
-        if self._gen is not None:
-            if not force:
-                return False
+        if force:
             while not self.pump(1 << 30):
                 pass
-        flag = torch.tensor([1 if (force or self.ready()) else 0], dtype=torch.int32, device="cuda")
+        flag = torch.tensor([1 if (force or (self._gen is None and self.ready())) else 0], dtype=torch.int32, device="cuda")
         if torch.distributed.is_available() and torch.distributed.is_initialized():
             torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN, group=self.process_group)
         if int(flag.item()) == 0:

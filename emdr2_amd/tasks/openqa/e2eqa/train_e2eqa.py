@@ -49,7 +49,10 @@ def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler,
         sink.finish()                                # buckets were all-reduced while the backward ran
     else:
         allreduce_gradients(model, dp_group)
-    optimizer.step(lr=lr_scheduler.step())
+    # the reference steps the optimizer with the rate its scheduler set at the END of the previous iteration (training.py:223-228,
+    # learning_rates.py:73-80): step n runs at lr(n - 1), so the very first update of a warm-up schedule has lr 0
+    optimizer.step(lr=lr_scheduler.get_lr())
+    lr_scheduler.step()
     return loss_reduced
 
 
@@ -153,7 +156,8 @@ def setup_model_and_optimizer(model_provider):
     num_iters = args.lr_decay_iters if args.lr_decay_iters is not None else args.train_iters
     num_iters = max(1, num_iters)
     lr_scheduler = AnnealingLR(args.lr, warmup_iter=args.warmup * num_iters, total_iters=num_iters, min_lr=args.min_lr)
-    args.iteration = checkpointing.load_checkpoint(args.load, model, None if args.no_load_optim else optimizer, lr_scheduler) if args.load else 0
+    no_optim = args.no_load_optim or getattr(args, 'finetune', False)                  # checkpointing.py:243-256: schedule only with the optimizer
+    args.iteration = checkpointing.load_checkpoint(args.load, model, None if no_optim else optimizer, None if no_optim else lr_scheduler) if args.load else 0
     if args.iteration == 0:
         model.init_state_dict_from_dpr_and_t5(args.pretrained_t5_load, args.pretrained_dpr_load)      # training.py:156-158
     return model, optimizer, lr_scheduler
@@ -163,7 +167,7 @@ def _save(iteration, model, optimizer, lr_scheduler):
     args = get_args()
     rank, world = _dp()
     checkpointing.save_checkpoint(args.save, iteration, model, None if args.no_save_optim else optimizer, lr_scheduler, rank=rank,
-                                  barrier=torch.distributed.barrier if world > 1 else None)
+                                  barrier=torch.distributed.barrier if world > 1 else None, args=args)
 
 
 def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_of_epoch_callback, end_of_epoch_callback2, eos_id, indexer=None):

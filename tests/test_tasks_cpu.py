@@ -89,3 +89,52 @@ def test_openqa_dataset_reads_the_reference_file_format(tmp_path):
     assert s["dec_ids"][0] == t.bos_token_id and t.eos_token_id in s["labels"] and s["reference"] == ["the emperor", "emperor"]
     b = collate([ds[0], ds[1]])
     assert b["query_ids_bert"].shape == (2, 16) and b["loss_mask"].dtype.is_floating_point and b["query_uid"].tolist() == [-1, -2]
+
+
+def test_checkpoint_files_carry_version_and_release_checkpoints_restart_the_run(tmp_path, monkeypatch):
+    """(i) files written here must say checkpoint_version 1.0 (the reference re-orders the QKV rows of version-0 files on load,
+    megatron/checkpointing.py:236 + transformer.py:225-248); (ii) a 'release' tracker means iteration 0 and no optimizer / schedule state
+    (checkpointing.py:196-204,243-256); (iii) version-0 files are refused instead of being read with scrambled rows."""
+    import pytest
+    from emdr2_amd import checkpointing as ck
+
+    monkeypatch.setattr(ck, "emdr2_state_dict", lambda model: {"w": torch.ones(2)})
+    monkeypatch.setattr(ck, "_invalidate_weight_caches", lambda: None)
+    loaded = {}
+    monkeypatch.setattr(ck, "load_emdr2_state_dict", lambda model, sd, strict=True: loaded.update(sd))
+
+    class Opt(object):
+        def __init__(self): self.got = None
+        def state_dict(self): return {"step": 3, "state": {}}
+        def load_state_dict(self, sd): self.got = sd
+
+    class Sched(Opt):
+        def state_dict(self): return {"num_iters": 7}
+
+    d = str(tmp_path / "ckpt")
+    ck.save_checkpoint(d, 40, object(), Opt(), Sched(), args={"lr": 1.0})
+    raw = torch.load(ck.get_checkpoint_name(d, 40), weights_only=False)
+    assert raw["checkpoint_version"] == 1.0 and raw["iteration"] == 40 and raw["args"] == {"lr": 1.0}
+    opt, sched = Opt(), Sched()
+    assert ck.load_checkpoint(d, object(), opt, sched) == 40 and opt.got["step"] == 3 and sched.got["num_iters"] == 7
+    # without the optimizer the schedule is not restored either (reference: both or neither)
+    sched2 = Sched()
+    assert ck.load_checkpoint(d, object(), None, sched2) == 40 and sched2.got is None
+    # release: weights only, iteration 0
+    import os, shutil
+    os.makedirs(os.path.dirname(ck.get_checkpoint_name(d, 0, release=True)))
+    shutil.copy(ck.get_checkpoint_name(d, 40), ck.get_checkpoint_name(d, 0, release=True))
+    open(ck.get_checkpoint_tracker_filename(d), "w").write("release")
+    opt, sched = Opt(), Sched()
+    assert ck.load_checkpoint(d, object(), opt, sched) == 0 and opt.got is None and sched.got is None and "w" in loaded
+    # version 0 is refused
+    raw.pop("checkpoint_version")
+    torch.save(raw, ck.get_checkpoint_name(d, 0, release=True))
+    with pytest.raises(ValueError):
+        ck.load_checkpoint(d, object())
+    # a reference-format optimizer state gives a pointer to --no-load-optim instead of a KeyError
+    class BadOpt(Opt):
+        def load_state_dict(self, sd): raise KeyError("step")
+    open(ck.get_checkpoint_tracker_filename(d), "w").write("40")
+    with pytest.raises(ValueError, match="no-load-optim"):
+        ck.load_checkpoint(d, object(), BadOpt(), None)
