@@ -8,7 +8,7 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")
+LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")     # tools/ may point this at lib/libemdr2_hip_exp.so (`make exp`) before first use
 
 EMDR2_ABI_VERSION = 1
 FLAG_AMBIGUOUS = 1

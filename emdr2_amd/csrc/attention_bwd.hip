@@ -304,7 +304,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
                     if (!qv) pr = 0.f;                                    // rows beyond sq do not exist
                     float gr = pacc[r], pd = pr;
                     if (drop) {
-                        const uint32_t bits = emdr2_mix32(colmul ^ rhv[e]);
+                        const uint32_t bits = emdr2_pair_bits_prod(rhv[e], colmul);
                         const bool keep = (codd ? (bits >> 16) : (bits & 0xffffu)) >= thr;
                         gr = keep ? gr * ik : 0.f;
                         pd = keep ? pr * ik : 0.f;

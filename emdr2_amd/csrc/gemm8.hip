@@ -47,6 +47,8 @@ struct G8Params {
     // LSE mode (lse_part != nullptr): nothing is stored to C; per (row, n-tile) partial max / sum-exp and the gold logit are written instead
     float *lse_max, *lse_sum, *lse_gold;
     const long long *labels;
+    int stagger;               // XCD start stagger: 1/64ths of a 1,024-cycle nap per K-tile and XCD index, 0 = off
+    int ablate;                // -DEMDR2_EXPERIMENTS builds only (EMDR2_G8_ABLATE): 1 = no epilogue, 2 = epilogue without global stores
 };
 
 __device__ __forceinline__ void tile_coords(const G8Params &p, int pos, int &tm, int &tn)
@@ -169,6 +171,14 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+    // ---- XCD stagger.  Every tile takes the same time, so without this all 256 CUs reach their epilogues together and 33 MB of output hits
+    // the memory system as one burst per tile period (the store issue then stalls for microseconds).  XCD x starts x/8 of a tile period late:
+    // the eight L2s write back in turn, each absorbs its own 4 MB burst, and the CUs of one XCD (who share operand panels) stay in step.
+    if (p.stagger) {
+        const int naps = (xcd * KT * p.stagger) >> 6;             // s_sleep 16 = 1,024 cycles; stagger / 64 = naps per K-tile and XCD index
+        for (int i = 0; i < naps; ++i) __builtin_amdgcn_s_sleep(16);
+    }
+
     // ---- prologue: the first six half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
     G8_STAGE(0, 0); G8_STAGE(1, 0); G8_STAGE(2, 0); G8_STAGE(3, 0); G8_STAGE(0, 1); G8_STAGE(1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0 of K-tile 0 have landed (this wave's pieces)
@@ -233,24 +243,50 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
         char *stg = smem + G8_STAGING + wave * 4096;            // wave-private: 32 rows x 64 bf16, 8-B slots XOR-swizzled with (row & 15)
         const int prow = elane >> 3, pc16 = elane & 7;           // row-order pass: 8 lanes cover one 128-byte row segment, 8 rows per pass
 
+#ifdef EMDR2_EXPERIMENTS
+        if (p.ablate == 1) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni) {
+                    asm volatile("" ::"v"(acc[mi][ni]));
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+                }
+            if (wr == 1) { G8_BARRIER(); }
+            continue;
+        }
+#endif
         constexpr bool LSE = (EPI & G8_LSE) != 0, HAS_BIAS = (EPI & G8_BIAS) != 0, HAS_RES = (EPI & (G8_RADD | G8_RGELU)) != 0;
         if constexpr (!LSE) {
             const float keep_scale = emdr2_keep_scale(p.drop_p);
             const uint32_t thr = emdr2_drop_thr(p.drop_p);
             constexpr int npass = (EPI & G8_PRE) ? 2 : 1;         // with a pre-activation output: one pass for it, one for the activation
-            // residual block of this wave in row order: all sixteen 16-byte loads go out before any math (the operand registers of the main
-            // loop are free now), so one HBM latency is exposed per tile instead of one per 32-row slab
-            uint4 rr[4][4];
-            if constexpr (HAS_RES) {
+            // this lane's place in the row-order pass: row prow (+ 8 per pass, + 32 per slab), 16-byte column group pc16; one 64-bit multiply
+            // per tile, everything else is a wave-uniform multiple of the row pitch
+            const long long lane_off = ((long long)(m_w + prow) * p.ldc + n_w + pc16 * 8) * 2;
+            const long long pitch8 = p.ldc * 16;                  // bytes per 8 rows
+            // bias of the 32 columns this lane holds in accumulator order: loaded ONCE per tile and BEFORE the residual rows (vmcnt retires
+            // in order: a bias load issued behind them would make its first use wait for the whole residual block)
+            float bcol[2][16];
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
+            for (int ni = 0; ni < 2; ++ni)
 #pragma unroll
-                    for (int ps = 0; ps < 4; ++ps) {
-                        const u32x4_t t = __builtin_nontemporal_load(
-                            (const u32x4_t *)((const uint16_t *)p.R + (long long)(m_w + mi * 32 + ps * 8 + prow) * p.ldc + n_w + pc16 * 8));
-                        rr[mi][ps] = make_uint4(t.x, t.y, t.z, t.w);
-                    }
-            }
+                for (int j = 0; j < 4; ++j) {
+                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if constexpr (HAS_BIAS) t = *(const float4 *)(p.bias + n_w + ni * 32 + 8 * j + 4 * ehi);
+                    bcol[ni][4 * j] = t.x; bcol[ni][4 * j + 1] = t.y; bcol[ni][4 * j + 2] = t.z; bcol[ni][4 * j + 3] = t.w;
+                }
+            // residual rows in row order, two 32-row slabs ahead of their use (the main loop's operand registers are free now)
+            uint4 rr[2][4];
+            auto load_res = [&](int mi, uint4(&dst)[4]) {
+#pragma unroll
+                for (int ps = 0; ps < 4; ++ps) {
+                    const u32x4_t t = __builtin_nontemporal_load((const u32x4_t *)(p.R + lane_off + (mi * 4 + ps) * pitch8));
+                    dst[ps] = make_uint4(t.x, t.y, t.z, t.w);
+                }
+            };
+            if constexpr (HAS_RES) { load_res(0, rr[0]); load_res(1, rr[1]); }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
@@ -261,12 +297,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                     for (int ni = 0; ni < 2; ++ni) {
                         float v[16];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                            if constexpr (HAS_BIAS) t = *(const float4 *)(p.bias + n_w + ni * 32 + 8 * j + 4 * ehi);
-                            v[4 * j] = fmaf(acc[mi][ni][4 * j], p.alpha, t.x); v[4 * j + 1] = fmaf(acc[mi][ni][4 * j + 1], p.alpha, t.y);
-                            v[4 * j + 2] = fmaf(acc[mi][ni][4 * j + 2], p.alpha, t.z); v[4 * j + 3] = fmaf(acc[mi][ni][4 * j + 3], p.alpha, t.w);
-                        }
+                        for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]);
                         if (final_pass) {
                             if constexpr ((EPI & G8_GELU) != 0) {
 #pragma unroll
@@ -274,11 +305,14 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                             }
                             if constexpr ((EPI & G8_DROP) != 0) {
                                 const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)m_l);
+                                // (col >> 1) * MUL of this lane's first pair; the other seven pairs are constant offsets from it
+                                const uint32_t prod0 = (uint32_t)((n_w + ni * 32 + 4 * ehi) >> 1) * EMDR2_PAIR_MUL;
 #pragma unroll
                                 for (int r = 0; r < 16; r += 2) {
-                                    const uint32_t bits = emdr2_pair_bits(rh, (uint32_t)(n_w + ni * 32 + 8 * (r >> 2) + 4 * ehi + (r & 3)));
-                                    v[r] = (bits & 0xffffu) >= thr ? v[r] * keep_scale : 0.f;
-                                    v[r + 1] = (bits >> 16) >= thr ? v[r + 1] * keep_scale : 0.f;
+                                    const uint32_t bits = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)((8 * (r >> 2) + (r & 3)) >> 1) * EMDR2_PAIR_MUL);
+                                    // a multiplicative mask (not a select on v): keeps the compiler from predicating the loads v depends on
+                                    v[r] *= (bits & 0xffffu) >= thr ? keep_scale : 0.f;
+                                    v[r + 1] *= (bits >> 16) >= thr ? keep_scale : 0.f;
                                 }
                             }
                         }
@@ -290,9 +324,9 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                                 make_uint2(pack2_bf16(v[4 * j], v[4 * j + 1]), pack2_bf16(v[4 * j + 2], v[4 * j + 3]));
                         }
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (same wave: the LDS executes its writes and reads in order; this pins the compiler)
+                    asm volatile("" ::: "memory");                       // compiler fence only: the LDS executes one wave's writes and reads in order
                     // LDS -> row order -> global
-                    char *outp = (final_pass ? p.C : p.C2);
+                    char *outp = (final_pass ? p.C : p.C2) + lane_off;
 #pragma unroll
                     for (int ps = 0; ps < 4; ++ps) {
                         const int row = ps * 8 + prow;
@@ -300,7 +334,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                         const uint2 hi2 = *(const uint2 *)(stg + row * 128 + (((2 * pc16 + 1) ^ (row & 15)) << 3));
                         uint32_t w[4] = {lo.x, lo.y, hi2.x, hi2.y};
                         if (HAS_RES && final_pass) {
-                            const uint32_t rw[4] = {rr[mi][ps].x, rr[mi][ps].y, rr[mi][ps].z, rr[mi][ps].w};
+                            const uint32_t rw[4] = {rr[mi & 1][ps].x, rr[mi & 1][ps].y, rr[mi & 1][ps].z, rr[mi & 1][ps].w};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float x0 = bf16_to_f32((uint16_t)(w[q] & 0xffff)), x1 = bf16_to_f32((uint16_t)(w[q] >> 16));
@@ -310,9 +344,15 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                                 w[q] = pack2_bf16(x0, x1);
                             }
                         }
-                        store_stream((uint16_t *)outp + (long long)(m_w + mi * 32 + row) * p.ldc + n_w + pc16 * 8, make_uint4(w[0], w[1], w[2], w[3]));
+#ifdef EMDR2_EXPERIMENTS
+                        if (p.ablate != 2 || w[0] == 0x12345678u)
+#endif
+                        store_stream((uint16_t *)(outp + (mi * 4 + ps) * pitch8), make_uint4(w[0], w[1], w[2], w[3]));
                     }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // reads of this slab are done before the next pass overwrites the staging rows
+                    asm volatile("" ::: "memory");                       // (the next pass's writes queue behind these reads in the same in-order LDS pipe)
+                }
+                if constexpr (HAS_RES) {
+                    if (mi + 2 < 4) load_res(mi + 2, rr[mi & 1]);
                 }
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)
@@ -376,6 +416,14 @@ int g8_cu_count()
     return cus;
 }
 
+int grid_for(const G8Params &p)
+{
+    int grid = g8_cu_count() & ~7;
+    if (grid < 8) grid = 8;
+    if (grid > ((p.total + 7) & ~7)) grid = (p.total + 7) & ~7;
+    return grid;
+}
+
 template <int EPI>
 int g8_launch(G8Params &p, hipStream_t stream)
 {
@@ -399,9 +447,15 @@ int g8_launch(G8Params &p, hipStream_t stream)
     const int last = p.tiles_n - (groups - 1) * p.ngroup;
     if ((long long)p.total >= (1ll << 24)) return -4;
     p.mg_full = magic((long long)p.ngroup * p.tiles_m); p.mg_group = p.ngroup > 1 ? magic(p.ngroup) : 0; p.mg_last = last > 1 ? magic(last) : 0;
-    int grid = g8_cu_count() & ~7;
-    if (grid < 8) grid = 8;
-    if (grid > ((p.total + 7) & ~7)) grid = (p.total + 7) & ~7;
+    // one K-tile takes ~3,200 shader cycles at the sustained rate; 1/8 of that per XCD index, in 1,024-cycle naps: 3200 / 8 / 1024 * 64 = 25
+    p.stagger = p.total >= 4 * grid_for(p) ? 25 : 0;             // only when every workgroup has several tiles to amortise the late start
+#ifdef EMDR2_EXPERIMENTS
+    static const int ablate_env = getenv("EMDR2_G8_ABLATE") ? atoi(getenv("EMDR2_G8_ABLATE")) : 0;
+    static const int stagger_env = getenv("EMDR2_G8_STAGGER") ? atoi(getenv("EMDR2_G8_STAGGER")) : -1;
+    p.ablate = ablate_env;
+    if (stagger_env >= 0) p.stagger = stagger_env;
+#endif
+    const int grid = grid_for(p);
     hipLaunchKernelGGL((gemm8_kernel<EPI>), dim3(grid), dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

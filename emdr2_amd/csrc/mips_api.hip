@@ -28,10 +28,17 @@ int cu_count()
 
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
+// Tuning / ablation switches are read from the environment ONLY in -DEMDR2_EXPERIMENTS builds (`make exp`, used by tools/); the production
+// library always runs the defaults, so a stray variable cannot change (or, with the ablations, corrupt) results.
 int env_int(const char *name, int dflt)
 {
+#ifdef EMDR2_EXPERIMENTS
     const char *v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
+#else
+    (void)name;
+    return dflt;
+#endif
 }
 
 struct Workspace {
@@ -148,7 +155,9 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         const uint16_t *qp = (const uint16_t *)queries + (size_t)q0 * dim;
         int rc;
         if ((rc = mips_launch_pack_queries(qp, nqp, dim, BN, w.q_tiled, w.qnorm, stream))) return rc;
+#ifdef EMDR2_EXPERIMENTS
         if (variant == 0 && scan_kernel == 5 && (rc = mips_launch_pack_queries_frag(qp, nqp, dim, w.q_frag, stream))) return rc;
+#endif
         const int64_t dense_rows = n_rows < seg0 ? n_rows : seg0;
         if ((rc = mips_launch_init(w.tau, w.count, out_flags + q0, BN, nqp, (unsigned)dense_rows, stream))) return rc;
 
@@ -186,6 +195,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
                 }
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n], stream) != hipSuccess) return EMDR2_E_LAUNCH;
             }
+#ifdef EMDR2_EXPERIMENTS
             if (mode == 0 && variant == 0 && ablate > 0) rc = mips_launch_scan_ablate(ablate, sp, grid, stream);
             else if (mode == 0 && variant == 0 && scan_kernel == 5) {
                 ScanParams sq = sp;
@@ -194,7 +204,9 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
             }
             else if (mode == 0 && scan_kernel == 2) rc = mips_launch_scan_pp(variant, 3, sp, grid, stream);
             else if (mode == 0 && scan_kernel == 4) rc = mips_launch_scan_pp(variant, seg_end == n_rows && done >= n_rows / 16 ? 4 : 3, sp, grid, stream);
-            else rc = mips_launch_scan(variant, mode, sp, grid, stream);
+            else
+#endif
+            rc = mips_launch_scan(variant, mode, sp, grid, stream);
             if (rc) return rc;
             if (timed) {
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n + 1], stream) != hipSuccess) return EMDR2_E_LAUNCH;

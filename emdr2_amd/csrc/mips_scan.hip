@@ -384,6 +384,7 @@ __device__ __forceinline__ void filter_tile_direct(const ScanParams &p, const fl
     if (__builtin_amdgcn_ballot_w64(stored)) wait_vmcnt0(); // keep the counted LDS-DMA waits exact
 }
 
+#ifdef EMDR2_EXPERIMENTS   // schedule variants kept for tools/ (ping-pong, q8): measured within +-4 % of the lockstep kernel, DESIGN 5.3
 template <int N> __device__ __forceinline__ void wait_vmcnt_n();
 template <> __device__ __forceinline__ void wait_vmcnt_n<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
 template <> __device__ __forceinline__ void wait_vmcnt_n<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
@@ -758,6 +759,7 @@ int mips_launch_scan_q8(int abl, const ScanParams &p, int grid, hipStream_t stre
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+#endif // EMDR2_EXPERIMENTS
 template <int WM, int WN, int MODE, int ABL = 0>
 static int launch_scan_t(const ScanParams &p, int grid, hipStream_t stream)
 {
@@ -772,6 +774,7 @@ static int launch_scan_t(const ScanParams &p, int grid, hipStream_t stream)
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
+#ifdef EMDR2_EXPERIMENTS
 int mips_launch_scan_ablate(int abl, const ScanParams &p, int grid, hipStream_t stream)
 {
     switch (abl) {
@@ -788,6 +791,7 @@ int mips_launch_scan_ablate(int abl, const ScanParams &p, int grid, hipStream_t 
     }
     return -1;
 }
+#endif
 
 int mips_launch_scan(int variant, int mode, const ScanParams &p, int grid, hipStream_t stream)
 {

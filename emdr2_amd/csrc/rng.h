@@ -22,8 +22,21 @@ __device__ __forceinline__ uint32_t emdr2_row_hash(uint32_t seed, unsigned long 
 {
     return emdr2_mix32((uint32_t)row ^ emdr2_mix32((uint32_t)(row >> 32) + seed * 0x9e3779b9u + 0x85ebca6bu));
 }
-// 32 random bits for the column pair (col & ~1, col | 1): low half for the even column, high half for the odd one
-__device__ __forceinline__ uint32_t emdr2_pair_bits(uint32_t rowhash, uint32_t col) { return emdr2_mix32(((col >> 1) * 0x9e3779b1u) ^ rowhash); }
+// 32 random bits for the column pair (col & ~1, col | 1): low half for the even column, high half for the odd one.
+// The row hash above is a full two-round mix; the per-pair step is deliberately light (xor-shift, one FULL-RATE 24-bit multiply, xor-shift:
+// 6 VALU ops where the earlier two-multiply finaliser cost ~22 issue slots with its quarter-rate 32-bit multiplies): in a GEMM epilogue
+// the pair hash is paid 4,096 times per lane-tile and was 60 % of the bias-dropout-add epilogue.  Keep rate, row / column sum variance,
+// lag-1..32 auto-correlation and cross-seed correlation of the resulting masks are at the sampling-noise level (same as the old hash).
+#define EMDR2_PAIR_MUL 0x9e3779b1u
+__device__ __forceinline__ uint32_t emdr2_pair_bits_prod(uint32_t rowhash, uint32_t pair_prod)     // pair_prod = (col >> 1) * EMDR2_PAIR_MUL
+{
+    uint32_t x = pair_prod ^ rowhash;
+    x ^= x >> 16;
+    x = (x & 0xffffffu) * 0xa2d2e5u;          // both factors < 2^24: v_mul_u32_u24
+    x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t emdr2_pair_bits(uint32_t rowhash, uint32_t col) { return emdr2_pair_bits_prod(rowhash, (col >> 1) * EMDR2_PAIR_MUL); }
 __device__ __forceinline__ bool emdr2_keep(uint32_t rowhash, uint32_t col, uint32_t thr)
 {
     const uint32_t b = emdr2_pair_bits(rowhash, col);
