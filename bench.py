@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""bench.py -- MIPS queries/s of the EMDR2 evidence search on MI355X (BASELINE.json configs[1]).
+"""bench.py -- both halves of BASELINE.json's metric on MI355X: MIPS queries/s of the EMDR2 evidence search (configs[1], the top-level
+fields of the JSON line) and QA train steps/s of the end-to-end EMDR2 step (configs[2], the `e2e` object; bench_e2e.py has the step).
 
 One "step" = one `search_mips_index` call: 512 fp16 queries against the 21,015,324 x 768 fp16
 evidence index resident in HBM, top-50, including query packing, the fused scan, candidate
@@ -13,6 +14,11 @@ Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the scan 
 last, largest row segment), timed with hipEvents on the launch stream inside the library;
 `cpu_baseline` times the oracle's CPU port (fp32-accumulate GEMM + top-k, all host cores) on a
 bounded row sample (rank 0, N = 1 only).
+
+`e2e` (after the MIPS region, same resident index): `steps_per_s` / `ms_per_step` of --e2e-steps training steps at B = 64 questions per
+GPU, top-k 50 (data-parallel over the N ranks, gradients averaged over RCCL); its `roofline` is for the step's dominant kernels, the
+dense linears: executed GEMM flops / per-launch hipEvent time summed inside the timed steps, against the 2.5 PFLOP/s bf16 MFMA peak, plus
+the whole-step MFU; its `cpu_baseline` is the fp32 oracle of the model path on the host cores (bounded sample, N = 1 only).
 """
 import argparse
 import ctypes
@@ -44,6 +50,12 @@ def parse():
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-e2e", action="store_true", help="MIPS half only")
+    ap.add_argument("--e2e-steps", type=int, default=3)
+    ap.add_argument("--e2e-warmup", type=int, default=1)
+    ap.add_argument("--e2e-timeout", type=float, default=420.0, help="seconds after which rank 0 prints the line without the e2e object and exits")
+    import bench_e2e
+    bench_e2e.add_args(ap)
     return ap.parse_args()
 
 
@@ -105,26 +117,34 @@ def main():
         torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
     from emdr2_amd import _native
-    from emdr2_amd.data.emdr2_index import HipIndexShard, merge_shard_results, shard_bounds
+    from emdr2_amd.data.emdr2_index import merge_shard_results, shard_bounds
+    import bench_e2e
     lib = _native.lib()
 
     lo, hi = shard_bounds(args.rows, world)[rank]
-    shard = HipIndexShard(DIM, hi - lo, lo)
-    for block in synth_rows(lo, hi):
-        shard.append_rows(block)
+    index = bench_e2e.build_index(args.rows, rank, world)              # this rank's row shard, shared by both halves of the benchmark
+    shard = index.shard
     gq = torch.Generator(device="cuda").manual_seed(4321)
     queries = torch.randn((args.queries, DIM), generator=gq, device="cuda", dtype=torch.float32).to(torch.float16)
     nq, k = args.queries, args.topk
 
+    merge_ms = []
+
     def step():
         dist, idx, row, flags = shard.search(queries, k, exact_fallback=False)
         if world > 1:
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)] if len(merge_ms) < 4096 else None
+            if ev:
+                ev[0].record()
             packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
             gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)  # concatenated along dim 0
             torch.distributed.all_gather_into_tensor(gathered, packed)
             gathered = gathered.view(world, 3, nq, k)
             dist, idx, row = merge_shard_results(gathered[:, 0].to(torch.int16).view(torch.float16).contiguous(),
                                                  gathered[:, 1].to(torch.int32).contiguous(), gathered[:, 2].contiguous())
+            if ev:
+                ev[1].record()
+                merge_ms.append(ev)
         return dist, idx, flags
 
     def fence():
@@ -183,6 +203,11 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    exchange_ms = None
+    if world > 1 and merge_ms:
+        timed = merge_ms[-args.steps:]
+        exchange_ms = sum(a.elapsed_time(b) for a, b in timed) / len(timed)
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         flops = 2.0 * nq * big * DIM
@@ -217,13 +242,47 @@ def main():
                                    % (k, nq, args.rows, DIM),
                        "rows": args.rows, "dim": DIM, "queries_per_step": nq, "top_k": k,
                        "parallelism": "index row-sharded x%d, all-gather(top-k) + merge" % world,
-                       "cus": int(lib.emdr2_device_cu_count()), "unproven_queries": flags_total},
+                       "cus": int(lib.emdr2_device_cu_count()), "unproven_queries": flags_total,
+                       # what makes the 1 -> N curve interpretable: rows scanned per rank, bytes every rank contributes to the ONE
+                       # all-gather of a search, and the time from the all-gather to the merged result (rank 0, hipEvents)
+                       "rows_per_rank": [b - a for a, b in shard_bounds(args.rows, world)],
+                       "allgather_bytes_per_rank": (3 * nq * k * 8) if world > 1 else 0,
+                       "allgather_plus_merge_ms": exchange_ms},
             "roofline": roofline,
         }
         if hbm_regime is not None:
             result["roofline_hbm_regime"] = hbm_regime
         if world == 1 and not args.no_cpu_baseline:
             result["cpu_baseline"] = cpu_baseline(args, queries.cpu().numpy())
+    else:
+        result = None
+
+    # ---- second half of the metric: the end-to-end training step over the same resident index ---------------------------------------
+    if not args.no_e2e:
+        watchdog = None
+        if rank == 0:
+            import threading
+
+            def give_up():
+                result["e2e"] = {"error": "end-to-end step did not finish within %.0f s" % args.e2e_timeout}
+                print(json.dumps(result), flush=True)
+                os._exit(0)
+            watchdog = threading.Timer(args.e2e_timeout, give_up)
+            watchdog.daemon = True
+            watchdog.start()
+        try:
+            del queries
+            ctx = bench_e2e.setup(args, rank, world, index=index, topk=k)
+            e2e = bench_e2e.run(ctx, args.e2e_steps, args.e2e_warmup, world)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                e2e["cpu_baseline"] = bench_e2e.cpu_baseline_subprocess(args.cpu_seconds)
+        except Exception as exc:                      # the MIPS half is still reported
+            e2e = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        if watchdog is not None:
+            watchdog.cancel()
+        if rank == 0:
+            result["e2e"] = e2e
+    if rank == 0:
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

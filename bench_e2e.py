@@ -4,10 +4,15 @@
 
 One step = query tower -> MIPS search over the resident index -> device-side evidence fetch + token assembly -> context tower ->
 reader encoder/decoder + the no-grad one-context reader pass -> EMDR2 loss -> backward (per-layer recompute) -> DP all-reduce ->
-Adam.  Prints ONE JSON line.  The driver's default benchmark stays `bench.py` (MIPS, configs[1]); this script reports the second
-half of BASELINE.json's metric ("QA train steps/sec").  Dropout is 0 (not built yet) - stated in `config`.
+Adam (train loop of the reference: tasks/openqa/e2eqa/train_e2eqa.py:468-513).  Hidden / attention dropout 0.1 as in the reference scripts.
+
+`bench.py` (the driver's benchmark) imports `setup` / `run` from here and reports this step as its `e2e` object next to the MIPS
+numbers; run directly, this script prints the step as its own ONE JSON line:
+
+    python bench_e2e.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--topk K] [--rows R] [--reindex-rows-per-step n]
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -19,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 MFMA_PEAK_TFLOPS = 2500.0
+H, L, V_T5, V_BERT = 768, 32, 30720, 30592
 
 
 def flops_per_step(B, K, S_ret, S, L, H, V, layers):
@@ -37,14 +43,8 @@ def flops_per_step(B, K, S_ret, S, L, H, V, layers):
     return 3 * (A + Bc + C + D) + E
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+def add_args(ap):
     ap.add_argument("--batch", type=int, default=64)
-    ap.add_argument("--topk", type=int, default=50)
-    ap.add_argument("--rows", type=int, default=21_015_324)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--seq-ret", type=int, default=256)
@@ -52,33 +52,32 @@ def main():
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
                     help="BASELINE configs[5]: re-embed this many evidence rows per training step on a side stream into the spare index image "
                          "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
-    args = ap.parse_args()
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("EMDR2_SINGLE_DEVICE"):          # dry run of the N-rank code path on a 1-GPU box: all ranks share cuda:0 (use with gloo)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")
-        torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
 
+
+def build_index(rows, rank, world):
+    """This rank's row shard of the synthetic evidence index (same generator as bench.py), inside a DistributedBruteForceIndex."""
     from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, shard_bounds
-    from emdr2_amd.data.evidence_arena import EvidenceArena
-    from emdr2_amd.model.emdr2_model import EMDR2Model, PreComputedEvidenceDocsRetriever, emdr2_loss
-    from emdr2_amd.model.transformer import Config
-    from emdr2_amd.training import FusedAdam, AnnealingLR, allreduce_gradients, get_params_for_weight_decay_optimization
     import bench as mips_bench
-
-    H, L, V_T5, V_BERT = 768, 32, 30720, 30592
-    B, K, S, S_ret = args.batch, args.topk, args.seq, args.seq_ret
-    # index shard + corpus (setup, untimed)
     index = DistributedBruteForceIndex(embed_size=H, embed_data=None, use_gpu=True)
-    lo, hi = shard_bounds(args.rows, world)[rank]
-    index.num_rows = args.rows
+    lo, hi = shard_bounds(rows, world)[rank]
+    index.num_rows = rows
     index.shard = index._make_shard(H, hi - lo, lo)
     for block in mips_bench.synth_rows(lo, hi):
         index.shard.append_rows(block)
     index.shard.set_ids(torch.arange(lo + 1, hi + 1, dtype=torch.int32, device="cuda"))
+    return index
+
+
+def setup(args, rank, world, index=None, topk=50):
+    """Model, optimizer, corpus, synthetic batch generator; returns a context with a `step()` callable."""
+    from emdr2_amd.data.evidence_arena import EvidenceArena
+    from emdr2_amd.model.emdr2_model import EMDR2Model, PreComputedEvidenceDocsRetriever, emdr2_loss
+    from emdr2_amd.model.transformer import Config
+    from emdr2_amd.training import FusedAdam, AnnealingLR, allreduce_gradients, get_params_for_weight_decay_optimization
+
+    B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
+    if index is None:
+        index = build_index(args.rows, rank, world)
     arena = EvidenceArena.synthetic(args.rows)
     retr = PreComputedEvidenceDocsRetriever.__new__(PreComputedEvidenceDocsRetriever)
     retr.args = types.SimpleNamespace(topk_retrievals=K, seq_length=S, seq_length_ret=S_ret)
@@ -91,7 +90,6 @@ def main():
     model.train()
     opt = FusedAdam(get_params_for_weight_decay_optimization(model), lr=2e-5, weight_decay=0.1, clip_grad=1.0)
     sched = AnnealingLR(2e-5, 10, 1000)
-    n_params = sum(p.numel() for p in model.parameters())
 
     sink = None
     if world > 1:                                                      # bucketed gradient all-reduce overlapped with the backward
@@ -136,8 +134,19 @@ def main():
             sink.finish()
         else:
             allreduce_gradients(model)
-        opt.step(lr=sched.step())
+        opt.step(lr=sched.get_lr())
+        sched.step()
         return loss
+
+    return types.SimpleNamespace(step=step, model=model, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+                                 layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
+
+
+def run(ctx, steps, warmup, world):
+    """W untimed + K timed steps between fences (barrier + synchronize), MAX over ranks; GEMM / attention time from the library's
+    per-launch hipEvents (recorded on the launch stream inside the timed region)."""
+    from emdr2_amd import _native
+    lib = _native.lib()
 
     def fence():
         torch.cuda.synchronize()
@@ -145,35 +154,130 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        loss = step()
+    loss = None
+    for _ in range(warmup):
+        loss = ctx.step()
     fence()
+    lib.emdr2_ops_set_timing(1)
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
+    for _ in range(steps):
+        loss = ctx.step()
     fence()
     elapsed = time.perf_counter() - t0
+    ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); nl = (ctypes.c_int64 * 4)()
+    _native.check(lib.emdr2_ops_timing_collect(ms, fl, nl, 4), "ops_timing_collect")
+    lib.emdr2_ops_set_timing(0)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+    fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)
+    sps = steps / elapsed
+    gemm_ms, gemm_fl = ms[0] + ms[1], fl[0] + fl[1]
+    gemm_tf = gemm_fl / (gemm_ms * 1e-3) / 1e12 if gemm_ms > 0 else 0.0
+    kinds = ("gemm_nt", "gemm_tn", "attention_fwd", "attention_bwd")
+    return {
+        "steps_per_s": sps * 1.0, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": "bf16", "scaling": "weak",
+        "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
+                               % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
+                   "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
+                   "dropout": ctx.dropout, "activation_recompute": "per layer", "loss": float(loss.detach()),
+                   "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+        # dominant kernels of the step: the dense linears (NT GEMM forward / input gradients, TN GEMM weight gradients)
+        "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "gemm_nt (gemm8_kernel / gemm_nt_kernel) + gemm_tn_kernel: executed flops / summed per-launch hipEvent time (rank 0)",
+                     "per_step": {k: {"ms": ms[i] / steps, "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0), "launches": int(nl[i] // steps)}
+                                  for i, k in enumerate(kinds)},
+                     "whole_step_mfu": {"tflops": fl_step * sps / 1e12, "frac": fl_step * sps / 1e12 / MFMA_PEAK_TFLOPS, "flops_per_step_per_gpu": fl_step,
+                                        "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"}},
+    }
+
+
+def cpu_baseline_subprocess(seconds=15.0, limit=120.0):
+    """cpu_baseline_model in a child process with a hard wall-clock limit (a slow host must not cost the benchmark its JSON line)."""
+    import subprocess
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    try:
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds)], env=env, timeout=limit,
+                             stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
+        return json.loads(out.strip().splitlines()[-1])
+    except Exception as exc:
+        return {"error": "%s: %s" % (type(exc).__name__, exc)}
+
+
+def cpu_baseline_model(seconds=20.0, layers=2, max_threads=64):
+    """The model path on the host cores: the torch-fp32 oracle restatement of the reference's forward / loss (oracle.transformer_oracle,
+    pinned on the reference's modules) + autograd backward at the BASELINE layer shapes (H = 768, 12 heads, FFN 3072, S_ret 256, S 512, L 32,
+    full vocabularies) on a BOUNDED sample -- B = 1, K = 2 and `layers` of the 12 layers of every stack -- with the rate scaled by dense-GEMM
+    flops to the 12-layer B = 64, K = 50 step.  kind "port".  The thread count is capped (tiny GEMMs on hundreds of threads run slower)."""
+    from oracle import transformer_oracle as to
+    cores = min(os.cpu_count() or 1, max_threads)
+    torch.set_num_threads(cores)
+    cfg = dict(layers=layers, hidden=H, heads=12, ffn=3072)
+    P = {k: v.requires_grad_(True) for k, v in to.random_params(cfg, V_BERT, V_T5).items()}
+    B, K, S_ret, S = 1, 2, 256, 512
+    g = torch.Generator().manual_seed(5)
+
+    def ids(shape, n_real):
+        x = torch.randint(5, 30522, shape, generator=g)
+        x[..., n_real:] = 0
+        return x
+    qb, ctx, ext, one, dec = ids((B, S_ret), 20), ids((B, K, S_ret), 180), ids((B * K, S), 400), ids((B * K, S), 220), ids((B, L), 6)
+    labels = torch.roll(dec, -1, 1)
+    mask = (labels != 0).float()
+
+    def step():
+        for p in P.values():
+            p.grad = None
+        lm, tlp, oc = to.emdr2_forward(P, cfg, qb, torch.zeros_like(qb), ~to.make_attention_mask_3d(qb, qb), ctx, torch.zeros_like(ctx), ext, one, dec)
+        loss = to.reader_ce_loss(lm, labels, mask) + to.retriever_loss_and_utility(oc, tlp, labels, mask, 30523)[0]
+        loss.backward()
+    t0 = time.perf_counter(); step(); t_first = time.perf_counter() - t0          # includes allocator warm-up
+    reps, t = 0, 0.0
+    while reps < 1 or (t + t_first + t / max(reps, 1) < seconds and reps < 5):
+        t0 = time.perf_counter(); step(); t += time.perf_counter() - t0; reps += 1
+    per = t / reps
+    scale = flops_per_step(64, 50, S_ret, S, L, H, V_T5, 12) / flops_per_step(B, K, S_ret, S, L, H, V_T5, layers)
+    return {"value": 1.0 / (per * scale), "unit": "steps/s", "cores": cores, "kind": "port",
+            "sample": "%d step(s) of the fp32 oracle (forward + loss + autograd backward, Adam excluded) at B=%d, K=%d, S_ret %d, S %d, L %d, "
+                      "%d of 12 layers per stack, torch CPU, %d threads: %.2f s/step; scaled x%.0f by dense-GEMM flops to 12 layers, B=64, K=50"
+                      % (reps, B, K, S_ret, S, L, layers, cores, per, scale)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--topk", type=int, default=50)
+    ap.add_argument("--rows", type=int, default=21_015_324)
+    ap.add_argument("--cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="print the host-core baseline of the model path as JSON and exit (no GPU)")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    add_args(ap)
+    args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_model(args.cpu_seconds)), flush=True)
+        return
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    if os.environ.get("EMDR2_SINGLE_DEVICE"):          # dry run of the N-rank code path on a 1-GPU box: all ranks share cuda:0 (use with gloo)
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")
+        torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+    ctx = setup(args, rank, world, topk=args.topk)
+    res = run(ctx, args.steps, args.warmup, world)
     if rank == 0:
-        fl = flops_per_step(B, K, S_ret, S, L, H, V_T5, args.layers)
-        sps = args.steps / elapsed
-        tf = fl * world * sps / 1e12
-        print(json.dumps({
-            "metric": "qa_train_steps_per_sec", "value": sps, "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
-            "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
-                                   % (B, K, S_ret, S, L, args.rows, args.layers),
-                       "global_batch": B * world, "params": n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
-                       "dropout": args.dropout, "activation_recompute": "per layer", "loss": float(loss.detach()),
-                       "reindex_rows_per_step": args.reindex_rows_per_step,
-                       "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
-            "roofline": {"bound": "mfma", "achieved": tf / world, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tf / world / MFMA_PEAK_TFLOPS,
-                         "traffic": None, "flops_per_step_per_gpu": fl, "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"},
-        }), flush=True)
+        out = {"metric": "qa_train_steps_per_sec", "value": res["steps_per_s"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "data": "synthetic", "config": res["config"], "roofline": res["roofline"]}
+        if args.cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_subprocess()
+        print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()
 

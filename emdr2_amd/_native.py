@@ -74,6 +74,12 @@ SIGNATURES.update({
 })
 
 
+SIGNATURES["emdr2_gemm_nt_lse_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
+SIGNATURES["emdr2_lse_combine"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp])
+SIGNATURES["emdr2_ops_set_timing"] = (_i32, [_i32])
+SIGNATURES["emdr2_ops_timing_collect"] = (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), _i32])
+
+
 class EvidenceArenaStruct(ctypes.Structure):
     """include/emdr2_assembly.h: emdr2_evidence_arena (device pointers)."""
     _fields_ = [("passage_tokens", _vp), ("passage_off", _vp), ("title_tokens", _vp), ("title_off", _vp),

@@ -19,6 +19,7 @@
 #include "rng.h"
 
 #include "attention_common.h"
+#include "ops_timing.h"
 
 namespace {
 
@@ -255,6 +256,7 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch;
     dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads));
+    OpsTimer timer(OPS_ATTN_FWD, 4.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
     hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -23,6 +23,7 @@
 #include "rng.h"
 
 #include "attention_common.h"
+#include "ops_timing.h"
 
 namespace {
 
@@ -382,6 +383,7 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dkv_sb = dkv_sb; p.dkv_ss = dkv_ss;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch;
+    OpsTimer timer(OPS_ATTN_BWD, 10.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
     hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(attn_grid((sq + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
     hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(attn_grid((sk + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;

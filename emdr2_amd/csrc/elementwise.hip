@@ -814,6 +814,36 @@ extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, int cols, floa
     return LAUNCH_OK();
 }
 
+// out[row] = gold[row] - logsumexp over the row's partials (max_j, sum_j exp(x - max_j)) written by emdr2_gemm_nt_lse_bf16: one wave per row
+__global__ void __launch_bounds__(256) lse_combine_kernel(const float *pmax, const float *psum, const float *gold, float *out, float *lse,
+                                                           long long rows, int slots)
+{
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float *pm = pmax + row * slots, *ps = psum + row * slots;
+    float m = -3.0e38f;
+    for (int i = lane; i < slots; i += 64) m = fmaxf(m, pm[i]);
+    m = wave_max(m);
+    float s = 0.f;
+    for (int i = lane; i < slots; i += 64) s += ps[i] * __expf(pm[i] - m);
+    s = wave_sum(s);
+    if (lane == 0) {
+        const float l = m + __logf(s);
+        if (lse) lse[row] = l;
+        out[row] = gold[row] - l;
+    }
+}
+
+extern "C" int emdr2_lse_combine(const float *part_max, const float *part_sum, const float *gold, float *out, float *lse, int64_t rows, int slots,
+                                 void *stream)
+{
+    if (!part_max || !part_sum || !gold || !out || rows < 1 || slots < 1) return -1;
+    hipLaunchKernelGGL(lse_combine_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, part_max, part_sum, gold, out, lse,
+                       (long long)rows, slots);
+    return LAUNCH_OK();
+}
+
 extern "C" int emdr2_lse_gather_fwd(const void *logits, const int64_t *labels, float *gold, float *lse, int64_t rows, int V, void *stream)
 {
     if (!logits || !labels || !gold || !lse || rows < 1 || V < 1) return -1;

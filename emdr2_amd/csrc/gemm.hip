@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "gemm_common.h"
+#include "ops_timing.h"
 
 #define GNST 3
 
@@ -348,6 +349,7 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;
     p.M = M; p.N = N; p.K = K; p.batch2 = batch2; p.alpha = alpha; p.gelu = gelu; p.out_f32 = out_f32; p.splitk = split_k; p.drop_p = drop_p; p.seed = seed;
     const int batch = batch1 * batch2;
+    OpsTimer timer(OPS_GEMM_NT, 2.0 * M * (double)N * K * batch, (hipStream_t)stream);
     if (batch == 1 && split_k == 1 && !out_f32) {
         // large unbatched linears: the persistent 256 x 256 x 64 kernel (gemm8.hip); -4 = shape not covered there
 #ifdef EMDR2_EXPERIMENTS

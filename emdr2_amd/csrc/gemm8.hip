@@ -26,6 +26,7 @@
 // each row's 256-column tile to (max, sum exp) and picks the gold logit, so the [tokens, vocab] matrix never reaches HBM.
 #include "../../include/emdr2_ops.h"
 #include "gemm_common.h"
+#include "ops_timing.h"
 #include <stdlib.h>
 
 namespace {
@@ -502,5 +503,6 @@ extern "C" int emdr2_gemm_nt_lse_bf16(const void *A, int64_t lda, const void *B,
     p.A = (const char *)A; p.B = (const char *)B; p.bias = bias;
     p.lda = lda; p.ldb = ldb; p.ldc = N; p.M = M; p.N = N; p.K = K; p.alpha = alpha;
     p.lse_max = part_max; p.lse_sum = part_sum; p.lse_gold = gold; p.labels = (const long long *)labels;
+    OpsTimer timer(OPS_GEMM_NT, 2.0 * M * (double)N * K, (hipStream_t)stream);
     return bias ? g8_launch<G8_LSE | G8_BIAS>(p, (hipStream_t)stream) : g8_launch<G8_LSE>(p, (hipStream_t)stream);
 }

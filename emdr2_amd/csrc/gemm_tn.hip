@@ -15,6 +15,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "ops_timing.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -211,6 +212,7 @@ extern "C" int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int
     }
     p.tiles_i = (I + 255) / 256; p.tiles_j = (J + 255) / 256;
     dim3 grid((unsigned)(((p.tiles_i * p.tiles_j * split_k + 7) / 8) * 8));
+    OpsTimer timer(OPS_GEMM_TN, 2.0 * I * (double)J * R, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(512), LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

@@ -106,6 +106,28 @@ from emdr2_amd.model import kernels as K  # noqa: E402
 from emdr2_amd.model.transformer import Config, DualEncoderModel, T5Model  # noqa: E402
 
 
+class OneContextLogits(object):
+    """`lm_logits_one_context` [B, K, L, V] of the reference (emdr2_model.py:185-210) in unevaluated form: the decoder states of the
+    no-grad one-context pass plus the tied LM head's parameters.  The EMDR2 loss only ever needs log_softmax(logits)[gold label]
+    (train_e2eqa.py:79-96), which `gold_logprob` computes inside the LM-head GEMM without writing the 6.3 GB logits tensor;
+    `materialize()` returns the reference's tensor for any other consumer."""
+
+    def __init__(self, hidden, weight, bias):
+        self.hidden, self.weight, self.bias = hidden, weight, bias                      # hidden [B, K, L, H] bf16
+
+    @property
+    def shape(self):
+        return tuple(self.hidden.shape[:3]) + (self.weight.shape[0],)
+
+    def gold_logprob(self, labels_bkl):
+        with torch.no_grad():
+            return K.lm_head_gold_logprob(self.hidden, self.weight, self.bias, labels_bkl)
+
+    def materialize(self):
+        with torch.no_grad():
+            return K.linear(self.hidden, self.weight, self.bias)
+
+
 class EMDR2Model(torch.nn.Module):
     """reference: megatron/model/emdr2_model.py:31-247.  Same sub-module names (`language_model`, `retriever_model`), same
     checkpoint keys ('encoder/t5_model', 'retriever/biencoder_model'), same training-mode return triple
@@ -129,6 +151,7 @@ class EMDR2Model(torch.nn.Module):
         self.disable_retriever_dropout = disable_retriever_dropout                  # --disable-retriever-dropout (arguments.py:558)
         self.no_query_embedder_training = no_query_embedder_training              # emdr2_model.py:103-104
         self.no_context_embedder_training = no_context_embedder_training          # emdr2_model.py:130-131
+        self.fuse_lm_head_loss = True          # one-context pass: LM head + log-softmax + gather in one GEMM (OneContextLogits); False = reference tensor
 
     def retriever_embedder(self, tokens, mask, types, embedder_type, disable_dropout=False):
         tower = self.retriever_model.query_model if embedder_type == "query" else self.retriever_model.context_model
@@ -176,7 +199,12 @@ class EMDR2Model(torch.nn.Module):
                 K.DROPOUT.pass_id = 1                                                         # a second, independent draw of every dropout site
                 try:
                     enc1 = self.language_model.encode(qone)
-                    one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
+                    if self.fuse_lm_head_loss:
+                        hid = self.language_model.decode_hidden(dec_rep, enc1, qone)
+                        one = OneContextLogits(hid.reshape(B, Kk, dec_ids.shape[1], H), self.language_model.language_model.embedding.word_embeddings.weight,
+                                               self.language_model.lm_head.bias)
+                    else:
+                        one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
                 finally:
                     K.DROPOUT.pass_id = 0
         if not self.training:
@@ -216,7 +244,11 @@ def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_ma
     if lm_logits_one_context is not None:
         Kk = lm_logits_one_context.shape[1]
         lab = labels.masked_fill(~loss_mask.to(torch.bool), 0)
-        gold1 = K.lse_gather(lm_logits_one_context, lab.unsqueeze(1).expand(-1, Kk, -1).contiguous()).detach()   # [B, K, L]
+        labk = lab.unsqueeze(1).expand(-1, Kk, -1).contiguous()
+        if isinstance(lm_logits_one_context, OneContextLogits):
+            gold1 = lm_logits_one_context.gold_logprob(labk)                                                   # [B, K, L], logits never stored
+        else:
+            gold1 = K.lse_gather(lm_logits_one_context, labk).detach()
         if ret_kldiv:                                                                         # --ret-kldiv (train_e2eqa.py:184-214)
             teacher_log = torch.sum(gold1 * mask.unsqueeze(1), dim=2) / torch.sum(mask.unsqueeze(1), dim=2)
             retriever_loss = torch.nn.functional.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='batchmean')

@@ -541,3 +541,30 @@ class LseGatherFn(torch.autograd.Function):
 
 def lse_gather(logits, labels):
     return LseGatherFn.apply(logits, labels)
+
+
+def lm_head_gold_logprob(hidden, weight, bias, labels):
+    """gold[row] = log_softmax(hidden[row] W^T + b)[labels[row]] (fp32) WITHOUT materialising the [rows, vocab] logits: the tied LM head
+    (language_model.py:28-41) and the log-softmax + gather of train_e2eqa.py:79-96 in one GEMM whose epilogue keeps, per row and 64-column
+    block, only (max, sum exp) and the gold logit (csrc/gemm8.hip LSE mode) plus a small combine kernel.  Logits are rounded to bf16 inside
+    the epilogue exactly as the unfused path stores them, so both paths agree.  No gradient: this is the no-grad one-context pass
+    (emdr2_model.py:185-210), whose [B, K, L, V] logits are 6.3 GB at the benchmark shape."""
+    _check_bf16(hidden)
+    V, H = weight.shape
+    h2 = hidden.reshape(-1, H)
+    M = h2.shape[0]
+    lab = labels.reshape(-1).contiguous()
+    if lab.numel() != M or lab.dtype != torch.int64:
+        raise ValueError("one int64 label per row expected")
+    if M % 256 or V % 256 or H % 128 or not h2.is_contiguous():
+        return lse_gather(linear(h2, weight, bias), lab).reshape(labels.shape)           # shapes the fused kernel does not take
+    slots = V // 64
+    dev = hidden.device
+    pmax = torch.empty((M, slots), dtype=torch.float32, device=dev)
+    psum = torch.empty_like(pmax)
+    gold = torch.empty(M, dtype=torch.float32, device=dev)
+    out = torch.empty_like(gold)
+    _native.check(_lib().emdr2_gemm_nt_lse_bf16(h2.data_ptr(), H, w_bf16(weight).data_ptr(), H, M, V, H, 1.0, _ptr(bias.detach() if bias is not None else None),
+                                                lab.data_ptr(), pmax.data_ptr(), psum.data_ptr(), gold.data_ptr(), _sp()), "gemm_nt_lse")
+    _native.check(_lib().emdr2_lse_combine(pmax.data_ptr(), psum.data_ptr(), gold.data_ptr(), out.data_ptr(), None, M, slots, _sp()), "lse_combine")
+    return out.reshape(labels.shape)

@@ -273,8 +273,12 @@ class T5Model(torch.nn.Module):
     def encode(self, encoder_input_ids):
         return self.language_model.encode(encoder_input_ids)
 
+    def decode_hidden(self, decoder_input_ids, enc_hidden_states, enc_ids):
+        """Decoder output before the LM head (for consumers that fuse the head with what follows it)."""
+        return self.language_model.decode(decoder_input_ids, enc_hidden_states, enc_ids)
+
     def decode(self, decoder_input_ids, enc_hidden_states, enc_ids):
-        dec = self.language_model.decode(decoder_input_ids, enc_hidden_states, enc_ids)
+        dec = self.decode_hidden(decoder_input_ids, enc_hidden_states, enc_ids)
         return self.lm_head(dec, self.language_model.embedding.word_embeddings.weight)
 
     def forward(self, encoder_input_ids, decoder_input_ids):

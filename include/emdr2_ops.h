@@ -117,6 +117,23 @@ int emdr2_adam_step(float *master, const float *grad, float *m, float *v, void *
 int emdr2_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
 int emdr2_accum_bf16_to_f32(const void *src, float *dst, int64_t n, float scale, void *stream);
 
+/* C[m, n-tile partials]: the tied LM head without the logits (language_model.py:28-41 + the log-softmax / gather of
+ * train_e2eqa.py:79-96).  For x[m, n] = bf16(alpha * sum_k A[m,k] B[n,k] + bias[n]) -- the value the unfused path would have stored -- writes per
+ * row m and per 64-column block j (N / 64 of them): part_max[m, j] = max_n x, part_sum[m, j] = sum_n exp(x - part_max), and gold[m] =
+ * x[m, labels[m]].  emdr2_lse_combine turns them into gold - logsumexp.  M % 256 == 0, N % 256 == 0, K % 128 == 0. */
+int emdr2_gemm_nt_lse_bf16(const void *A, int64_t lda, const void *B, int64_t ldb, int M, int N, int K, float alpha, const float *bias,
+                           const int64_t *labels, float *part_max, float *part_sum, float *gold, void *stream);
+
+/* out[row] = gold[row] - logsumexp(row) from the per-block partials of emdr2_gemm_nt_lse_bf16 (slots = N / 64); lse optional. */
+int emdr2_lse_combine(const float *part_max, const float *part_sum, const float *gold, float *out, float *lse, int64_t rows, int slots,
+                      void *stream);
+
+/* Measurement hooks (bench.py): with timing on, every GEMM / attention launch of this library is bracketed by hipEvents recorded on its launch
+ * stream.  collect() waits for them and returns, per kind (0 NT GEMM, 1 TN GEMM, 2 attention forward, 3 attention backward), the summed
+ * milliseconds, the summed algorithmic flops and the number of launches since the last set_timing / collect.  kinds >= 4. */
+int emdr2_ops_set_timing(int enabled);
+int emdr2_ops_timing_collect(double *ms, double *flops, int64_t *launches, int kinds);
+
 #ifdef __cplusplus
 }
 #endif

@@ -184,3 +184,53 @@ def annealing_lr(num_iters, start_lr, warmup_iter, end_iter, min_lr=0.0):
         return float(start_lr) * n_ / warmup_iter
     n_ = n_ - warmup_iter
     return max(start_lr * (end_iter - n_) / end_iter, min_lr)
+
+
+# ---- random parameters with the reference's names (bench.py cpu_baseline; shapes: language_model.py:98-181, transformer.py:58-563) --------
+def random_params(cfg, bert_vocab, t5_vocab, max_pos=512, std=0.02, seed=1234):
+    """Flat {name: fp32 tensor} for the two BERT towers and the reader, random-normal(0, std) weights / zero biases / unit LayerNorm gains,
+    cfg = dict(layers, hidden, heads, ffn)."""
+    g = torch.Generator().manual_seed(seed)
+    H, F_, L = cfg["hidden"], cfg["ffn"], cfg["layers"]
+    P = {}
+
+    def w(name, *shape):
+        P[name] = torch.randn(shape, generator=g) * std
+
+    def lin(prefix, n_out, n_in):
+        w(prefix + ".weight", n_out, n_in)
+        P[prefix + ".bias"] = torch.zeros(n_out)
+
+    def ln(prefix):
+        P[prefix + ".weight"] = torch.ones(H)
+        P[prefix + ".bias"] = torch.zeros(H)
+
+    def stack(prefix, decoder):
+        for i in range(L):
+            lp = "%s.layers.%d" % (prefix, i)
+            ln(lp + ".input_layernorm")
+            lin(lp + ".self_attention.query_key_value", 3 * H, H)
+            lin(lp + ".self_attention.dense", H, H)
+            ln(lp + ".post_attention_layernorm")
+            if decoder:
+                lin(lp + ".inter_attention.query", H, H)
+                lin(lp + ".inter_attention.key_value", 2 * H, H)
+                lin(lp + ".inter_attention.dense", H, H)
+                ln(lp + ".post_inter_attention_layernorm")
+            lin(lp + ".mlp.dense_h_to_4h", F_, H)
+            lin(lp + ".mlp.dense_4h_to_h", H, F_)
+        ln(prefix + ".final_layernorm")
+
+    def lm(prefix, vocab, decoder):
+        w(prefix + ".embedding.word_embeddings.weight", vocab, H)
+        w(prefix + ".embedding.position_embeddings.weight", max_pos, H)
+        w(prefix + ".embedding.tokentype_embeddings.weight", 2, H)
+        stack(prefix + ".encoder", False)
+        if decoder:
+            stack(prefix + ".decoder", True)
+
+    lm("retriever_model.query_model.language_model", bert_vocab, False)
+    lm("retriever_model.context_model.language_model", bert_vocab, False)
+    lm("language_model.language_model", t5_vocab, True)
+    P["language_model.lm_head.bias"] = torch.zeros(t5_vocab)
+    return P

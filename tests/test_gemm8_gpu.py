@@ -124,3 +124,23 @@ def test_gemm8_agrees_with_the_general_kernel():
     fast = _gemm(A[:M].contiguous(), B, bias=bias)
     assert float((general != fast).float().mean()) < 1e-3
     assert torch.allclose(general.float(), fast.float(), rtol=1e-2, atol=1e-2)
+
+
+@pytest.mark.parametrize("M,V,H", [(4096, 30720, 768), (2048, 1024, 128), (256, 512, 256)])
+def test_lm_head_fused_with_log_softmax_gather(M, V, H):
+    """The LSE epilogue (LM head + log-softmax + gold gather, logits never stored) against the unfused kernels on the same operands, and
+    against an fp32 torch reference (language_model.py:28-41 + train_e2eqa.py:79-96)."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(M + V)
+    hid = _rand((M, H), g)
+    W = torch.nn.Parameter(torch.randn((V, H), generator=g, device="cuda") * 0.05)
+    bias = torch.nn.Parameter(torch.randn(V, generator=g, device="cuda") * 0.1)
+    labels = torch.randint(0, V, (M,), generator=g, device="cuda")
+    labels[:7] = torch.tensor([0, 1, 63, 64, 255, 256, V - 1], device="cuda")          # block / tile boundaries
+    with torch.no_grad():
+        fused = K.lm_head_gold_logprob(hid, W, bias, labels)
+        logits = K.linear(hid, W, bias)
+        unfused = K.lse_gather(logits, labels)
+        ref = torch.log_softmax(hid.float() @ W.bfloat16().float().T + bias, dim=-1).gather(1, labels[:, None])[:, 0]
+    assert torch.allclose(fused, unfused, rtol=0, atol=2e-4), float((fused - unfused).abs().max())   # same bf16-rounded logits, different summation order
+    assert torch.allclose(fused, ref, rtol=2e-2, atol=5e-2)
