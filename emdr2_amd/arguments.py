@@ -1,7 +1,7 @@
 """Command-line flags of the QA task: the flag set of examples/openqa/emdr2_{nq,trivia,webq}.sh with the reference's names, types and
 defaults (megatron/arguments.py:24-596, tasks/run.py:24-67), so those scripts run against this package unchanged.  Flags that configure
-machinery this build replaces are accepted and recorded but have no effect: --fp16 (bf16 activations + fp32 masters here, no loss
-scaling), --DDP-impl, --distributed-backend, --num-workers, --faiss-use-gpu (the index always lives in HBM), --max-training-rank /
+machinery this build replaces are accepted and recorded but have no effect: --fp16 (announced at start-up as bf16 activations + fp32
+masters, no loss scaling: args.params_dtype), --DDP-impl, --distributed-backend, --num-workers, --faiss-use-gpu (the index always lives in HBM), --max-training-rank /
 --async-indexer's extra GPU group (re-indexing runs on a side stream of the trainers), --stale-checkpoint-path, --mmap-warmup.
 Unknown flags raise, like argparse in the reference."""
 import argparse
@@ -122,4 +122,11 @@ def parse_args(argv=None):
     if args.load and args.ict_load:
         raise ValueError("--load and --ict-load are exclusive (indexer_emdr2.py:47)")
     args.iteration = 0
+    # the reference's --fp16 (fp16 activations, fp32 masters inside FP16_Optimizer, dynamic loss scaling) maps to this build's ONLY
+    # precision mode: bf16 activations and working weights, fp32 master weights and gradients, no loss scaling.  Said once, recorded in args.
+    args.params_dtype = 'bf16'
+    args.master_dtype = 'fp32'
+    if args.rank == 0:
+        print("emdr2_amd: %sbf16 activations / working weights with fp32 master weights and fp32 weight gradients; no loss scaling "
+              "(there is no fp16 or fp32 compute mode in this build)" % ("--fp16 requested -> " if args.fp16 else ""), flush=True)
     return args

@@ -32,69 +32,75 @@ def detach(tensor):
 
 
 class OpenRetreivalDataStore(object):
-    """Serializable {doc_id -> fp16[D]} store (reference: emdr2_index.py:16-100; the class name keeps
-    the reference's spelling).  File format is the reference's pickle so `--embedding-path`
-    artefacts interoperate."""
+    """Serializable {doc_id -> fp16[D]} store.  Boundary kept from the reference (emdr2_index.py:16-100; the class name keeps its
+    spelling): constructor arguments, `embed_data`, `add_block_data / save_shard / merge_shards_and_save / clear / load_from_file /
+    state`, and the two on-disk formats -- the final pickle `{'embed_data': {id: np.float16[D]}}` at `embedding_path` and one such pickle
+    per rank under `<embedding_path minus extension>_tmp/<rank>.pkl` -- so `--embedding-path` artefacts interoperate in both directions."""
 
     def __init__(self, embedding_path=None, load_from_path=True, rank=None):
-        self.embed_data = dict()
-        if embedding_path is None:
+        if embedding_path is None:                                # the reference's no-argument form: both come from the global args
             from emdr2_amd.global_vars import get_args
-            args = get_args()
-            embedding_path = args.embedding_path
-            rank = args.rank
-        self.embedding_path = embedding_path
-        self.rank = rank
-
+            embedding_path, rank = get_args().embedding_path, get_args().rank
+        self.embedding_path, self.rank = embedding_path, rank
+        self.temp_dir_name = os.path.splitext(embedding_path)[0] + '_tmp'
+        self.embed_data = {}
         if load_from_path:
             self.load_from_file()
 
-        block_data_name = os.path.splitext(self.embedding_path)[0]
-        self.temp_dir_name = block_data_name + '_tmp'
-
+    # -- the serialised form ------------------------------------------------------------------------------------------------------
     def state(self):
         return {'embed_data': self.embed_data}
 
+    @staticmethod
+    def _read(path):
+        with open(path, 'rb') as fh:
+            return pickle.load(fh)['embed_data']
+
+    def _write(self, path):
+        with open(path, 'wb') as fh:
+            pickle.dump(self.state(), fh)
+
+    def _shard_path(self, rank):
+        return os.path.join(self.temp_dir_name, '%d.pkl' % rank)
+
     def clear(self):
-        self.embed_data = dict()
+        self.embed_data = {}
 
     def load_from_file(self):
-        with open(self.embedding_path, 'rb') as f:
-            state_dict = pickle.load(f)
-        self.embed_data = state_dict['embed_data']
+        self.embed_data = self._read(self.embedding_path)
 
+    # -- filling ---------------------------------------------------------------------------------------------------------------------
     def add_block_data(self, row_id, block_embeds, allow_overwrite=False):
-        for idx, embed in zip(row_id, block_embeds):
-            if not allow_overwrite and idx in self.embed_data:
+        """Rows are stored as fp16 whatever they arrive as (emdr2_index.py:61); re-adding an id is an error unless allowed."""
+        ids = [int(i) for i in row_id]
+        if not allow_overwrite:
+            clash = [i for i in ids if i in self.embed_data]
+            if clash or len(set(ids)) != len(ids):
                 raise ValueError("Unexpectedly tried to overwrite block data")
-            self.embed_data[idx] = np.float16(embed)
+        rows = np.asarray(block_embeds, dtype=np.float16)
+        self.embed_data.update(zip(ids, rows))
 
+    # -- per-rank shards -> one file -------------------------------------------------------------------------------------------------
     def save_shard(self):
-        if not os.path.isdir(self.temp_dir_name):
-            os.makedirs(self.temp_dir_name, exist_ok=True)
-        with open('{}/{}.pkl'.format(self.temp_dir_name, self.rank), 'wb') as writer:
-            pickle.dump(self.state(), writer)
+        os.makedirs(self.temp_dir_name, exist_ok=True)
+        self._write(self._shard_path(self.rank))
 
     def merge_shards_and_save(self):
-        shard_names = os.listdir(self.temp_dir_name)
-        seen_own_shard = False
-        for fname in os.listdir(self.temp_dir_name):
-            shard_rank = int(os.path.splitext(fname)[0])
-            if shard_rank == self.rank:
-                seen_own_shard = True
+        """Called on ONE rank after every rank's `save_shard`: fold the other ranks' shard files into this store (ids must be disjoint,
+        this rank's own shard must be among the files), write the result to `embedding_path`, drop the shard directory."""
+        ranks = sorted(int(os.path.splitext(name)[0]) for name in os.listdir(self.temp_dir_name))
+        if self.rank not in ranks:
+            raise AssertionError("merge without this rank's own shard file (%s)" % self._shard_path(self.rank))
+        for r in ranks:
+            if r == self.rank:
                 continue
-            with open('{}/{}'.format(self.temp_dir_name, fname), 'rb') as f:
-                data = pickle.load(f)
-                old_size = len(self.embed_data)
-                shard_size = len(data['embed_data'])
-                self.embed_data.update(data['embed_data'])
-                assert len(self.embed_data) == old_size + shard_size
-        assert seen_own_shard
-        with open(self.embedding_path, 'wb') as final_file:
-            pickle.dump(self.state(), final_file)
+            other = self._read(self._shard_path(r))
+            if not self.embed_data.keys().isdisjoint(other.keys()):
+                raise AssertionError("shard %d repeats ids already merged" % r)
+            self.embed_data.update(other)
+        self._write(self.embedding_path)
         shutil.rmtree(self.temp_dir_name, ignore_errors=True)
-        print("Finished merging {} shards for a total of {} embeds".format(
-            len(shard_names), len(self.embed_data)), flush=True)
+        print("merged %d shard files: %d embeddings in %s" % (len(ranks), len(self.embed_data), self.embedding_path), flush=True)
 
     # ---- flat views (not in the reference): avoid 21M tiny arrays on the way to the GPU -----------
     def to_arrays(self):

@@ -14,10 +14,18 @@ from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, OpenRetreival
 
 
 class PreComputedEvidenceDocsRetriever(object):
-    def __init__(self, args, evidence_arena, process_group=None, embed_data=None):
-        """args: namespace with the reference's flags (topk_retrievals, hidden_size, allow_trivial_doc,
-        embedding_path, faiss_use_gpu, seq_length, seq_length_ret); evidence_arena: EvidenceArena built from the
-        reference's `passages_map` / `title_map` / evidence TSV (emdr2_model.py:401-408)."""
+    def __init__(self, args=None, evidence_arena=None, process_group=None, embed_data=None):
+        """`PreComputedEvidenceDocsRetriever()` -- the reference's form (emdr2_model.py:379-408): flags from `get_args()`, the evidence
+        (`--indexed-evidence-data-path`, `--indexed-title-data-path`, `--evidence-data-path`) loaded into an EvidenceArena in HBM, the
+        embeddings of `--embedding-path` into this rank's index shard.  Explicit arguments override: `args` = a namespace with the
+        reference's flags (topk_retrievals, hidden_size, allow_trivial_doc, embedding_path, faiss_use_gpu, seq_length, seq_length_ret),
+        `evidence_arena` = a prebuilt EvidenceArena, `embed_data` = an OpenRetreivalDataStore."""
+        if args is None:
+            from emdr2_amd.global_vars import get_args
+            args = get_args()
+        if evidence_arena is None:
+            from emdr2_amd.tasks.openqa.e2eqa.run import build_evidence_arena
+            evidence_arena = build_evidence_arena(args)
         self.args = args
         self.topk = args.topk_retrievals
         self.embedding_size = args.hidden_size
@@ -134,10 +142,27 @@ class EMDR2Model(torch.nn.Module):
     (lm_logits [B,L,V], topk_log_probs [B,K], lm_logits_one_context [B,K,L,V]).  Masks are derived from token ids inside the
     kernels, so `query_mask_bert` is accepted for signature compatibility and ignored."""
 
-    def __init__(self, evidence_retriever, cfg, t5_vocab_size, bert_vocab_size, topk, seq_length, seq_length_ret, cls_id, sep_id, pad_id=0,
-                 update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False, disable_retriever_dropout=False,
-                 no_query_embedder_training=False, no_context_embedder_training=False):
+    def __init__(self, evidence_retriever, cfg=None, t5_vocab_size=None, bert_vocab_size=None, topk=None, seq_length=None, seq_length_ret=None,
+                 cls_id=None, sep_id=None, pad_id=0, update_retriever=True, retriever_score_scaling=True, checkpoint_activations=False,
+                 disable_retriever_dropout=False, no_query_embedder_training=False, no_context_embedder_training=False):
+        """`EMDR2Model(evidence_retriever)` -- the reference's form (emdr2_model.py:31-61): architecture, sequence lengths, top-k and the
+        training switches from `get_args()`, vocabulary sizes and special ids from the global tokenizers.  Passing `cfg` and the rest
+        explicitly bypasses the globals (tests, bench)."""
         super().__init__()
+        if cfg is None:
+            from emdr2_amd.global_vars import get_args, get_t5_tokenizer
+            a = get_args()
+            t5_tok = get_t5_tokenizer()                                             # also fills a.{bert,t5}_padded_vocab_size
+            cfg = Config(num_layers=a.num_layers, hidden_size=a.hidden_size, num_attention_heads=a.num_attention_heads,
+                         ffn_hidden_size=a.ffn_hidden_size, max_position_embeddings=a.max_position_embeddings,
+                         layernorm_epsilon=a.layernorm_epsilon, init_method_std=a.init_method_std, hidden_dropout=a.hidden_dropout,
+                         attention_dropout=a.attention_dropout)
+            t5_vocab_size, bert_vocab_size = a.t5_padded_vocab_size, a.bert_padded_vocab_size
+            topk, seq_length, seq_length_ret = a.topk_retrievals, a.seq_length, a.seq_length_ret
+            cls_id, sep_id, pad_id = t5_tok.cls, t5_tok.sep, t5_tok.pad
+            update_retriever, retriever_score_scaling = a.update_retriever, a.retriever_score_scaling
+            checkpoint_activations, disable_retriever_dropout = a.checkpoint_activations, a.disable_retriever_dropout
+            no_query_embedder_training, no_context_embedder_training = a.no_query_embedder_training, a.no_context_embedder_training
         self.topk = topk
         self.language_model = T5Model(cfg, t5_vocab_size, 2, checkpoint_activations)
         self._language_model_key = 'encoder/t5_model'
@@ -217,10 +242,19 @@ class EMDR2Model(torch.nn.Module):
         return checkpointing.emdr2_state_dict(self)
 
     def load_state_dict_from_checkpoint(self, state, strict=True):
-        """emdr2_model.py:228-231 (`load_state_dict` there; torch's flat `load_state_dict` is left untouched here)."""
+        """emdr2_model.py:228-231: the nested checkpoint dict."""
         from emdr2_amd import checkpointing
         checkpointing.load_emdr2_state_dict(self, state, strict)
         K.WEIGHTS.invalidate()
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        """The reference's name for the above (emdr2_model.py:228-231 overrides nn.Module.load_state_dict with the nested form);
+        a flat torch state dict still goes to nn.Module."""
+        if self._language_model_key in state_dict or self._retriever_model_key in state_dict:
+            return self.load_state_dict_from_checkpoint(state_dict, strict)
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        K.WEIGHTS.invalidate()
+        return out
 
     def init_state_dict_from_dpr_and_t5(self, pretrained_t5_load, pretrained_dpr_load):
         """emdr2_model.py:233-247: iteration-0 initialisation from the pre-trained reader and dual encoder."""

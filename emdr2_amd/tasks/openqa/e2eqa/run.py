@@ -16,6 +16,9 @@ from emdr2_amd.tasks.openqa.e2eqa.train_e2eqa import accuracy_func_provider, pri
 
 def build_tokenizers(args):
     """megatron/global_vars.py:94-110: the retriever's tokenizer and the reader's (same vocabulary + 100 sentinel ids)."""
+    from emdr2_amd import global_vars
+    if global_vars._ARGS is args:
+        return global_vars.get_tokenizer(), global_vars.get_t5_tokenizer()
     bert_tokenizer = tok.build_tokenizer(args, vocab_extra_ids=0)
     args.bert_padded_vocab_size = args.padded_vocab_size
     t5_tokenizer = tok.build_tokenizer(args, vocab_extra_ids=100)

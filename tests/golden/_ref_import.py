@@ -17,8 +17,14 @@ REFERENCE_ROOT = "/root/reference"
 
 def install_import_shims():
     sys.dont_write_bytecode = True
-    if REFERENCE_ROOT not in sys.path:
+    # the repo root carries alias packages named `megatron` and `tasks` (drop-in names over emdr2_amd): the REFERENCE's packages must win here
+    if sys.path[:1] != [REFERENCE_ROOT]:
+        if REFERENCE_ROOT in sys.path:
+            sys.path.remove(REFERENCE_ROOT)
         sys.path.insert(0, REFERENCE_ROOT)
+    for name in [n for n in sys.modules if n.split(".")[0] in ("megatron", "tasks")]:
+        if not str(getattr(sys.modules[name], "__file__", "") or "").startswith(REFERENCE_ROOT):
+            del sys.modules[name]
     if "torch._six" not in sys.modules:
         six = types.ModuleType("torch._six")
         six.inf = float("inf")
