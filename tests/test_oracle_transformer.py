@@ -71,3 +71,44 @@ def test_kl_div_retriever_loss_matches_reference():
     ref = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ckpt_layout.json")))["kl"]
     got = to.retriever_kl_div_loss(torch.tensor(ref["one"]), torch.tensor(ref["tlp"]), torch.tensor(ref["labels"]), torch.tensor(ref["mask"]))
     assert abs(float(got) - ref["loss"]) < 1e-6 * max(1.0, abs(ref["loss"]))
+
+
+def test_base_size_layer_fixture_from_the_reference():
+    """F1 of SURVEY 8c at BASE size: the reference's ParallelTransformerLayer (transformer.py:422-563) as encoder layer (H 768, 12 heads,
+    FFN 3072, s 512) and decoder layer (s 32 over 512 encoder positions): output, input gradients and every parameter gradient of the oracle
+    against sampled values of the reference's own run (tests/golden/gen_layer_base_golden.py)."""
+    import os
+    import layer_base_case as lb
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "layer_base_ref.npz"))
+    inp = lb.inputs()
+    t = lambda k: torch.from_numpy(inp[k])
+    enc_ids, dec_ids = t("enc_ids"), t("dec_ids")
+    enc_out = None
+    for kind, seed in (("encoder", 11), ("decoder", 12)):
+        P = {"L." + k: torch.from_numpy(v).requires_grad_(True) for k, v in lb.layer_params(kind, seed).items()}
+        if kind == "encoder":
+            x = t("enc_x").clone().requires_grad_(True)
+            y = to.transformer_layer(P, "L", lb.DIMS["heads"], x, (~to.make_attention_mask_3d(enc_ids, enc_ids))[:, None])
+            w = t("w_enc")
+            enc_out = y.detach()
+        else:
+            x = t("dec_x").clone().requires_grad_(True)
+            enc = enc_out.clone().requires_grad_(True)
+            mask = (~(to.make_attention_mask_3d(dec_ids, dec_ids) * to.make_history_mask_3d(dec_ids)))[:, None]
+            ed = (~to.make_attention_mask_3d(dec_ids, enc_ids))[:, None]
+            y = to.transformer_layer(P, "L", lb.DIMS["heads"], x, mask, encoder_output=enc, enc_dec_mask=ed)
+            w = t("w_dec")
+        (y * w).sum().backward()
+
+        def check(name, got, tol=2e-4):
+            ref = g[name]
+            s = lb.sample(got.detach().numpy())
+            scale = max(1e-6, float(np.abs(ref[2:]).max()))
+            assert np.abs(s[2:] - ref[2:]).max() <= tol * scale, (name, np.abs(s[2:] - ref[2:]).max(), scale)
+            assert abs(s[1] - ref[1]) <= 1e-3 * ref[1] + 1e-6, name                    # absolute sum of the whole tensor
+        check(kind + ".out", y)
+        check(kind + ".dx", x.grad)
+        if kind == "decoder":
+            check(kind + ".denc", enc.grad)
+        for k in lb.layer_params(kind, seed):
+            check(kind + ".grad." + k, P["L." + k].grad, tol=5e-4)
