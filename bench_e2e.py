@@ -73,7 +73,8 @@ def setup(args, rank, world, index=None, topk=50):
     from emdr2_amd.data.evidence_arena import EvidenceArena
     from emdr2_amd.model.emdr2_model import EMDR2Model, PreComputedEvidenceDocsRetriever, emdr2_loss
     from emdr2_amd.model.transformer import Config
-    from emdr2_amd.training import FusedAdam, AnnealingLR, allreduce_gradients, get_params_for_weight_decay_optimization
+    from emdr2_amd.training import FlatAdam, AnnealingLR
+    from emdr2_amd.model import kernels as Kmod
 
     B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
     if index is None:
@@ -88,14 +89,10 @@ def setup(args, rank, world, index=None, topk=50):
                  hidden_dropout=args.dropout, attention_dropout=args.dropout)
     model = EMDR2Model(retr, cfg, V_T5, V_BERT, K, S, S_ret, cls_id=101, sep_id=102, checkpoint_activations=True)
     model.train()
-    opt = FusedAdam(get_params_for_weight_decay_optimization(model), lr=2e-5, weight_decay=0.1, clip_grad=1.0)
+    # flat buckets: masters / gradients / moments / bf16 working copies back to back; ~20 optimizer launches per step; with world > 1 the
+    # buckets are all-reduced in bf16 (0.88 GB on the wire) as their last gradient arrives from the backward
+    opt = Kmod.GRAD_SINK = FlatAdam(model, lr=2e-5, weight_decay=0.1, clip_grad=1.0)
     sched = AnnealingLR(2e-5, 10, 1000)
-
-    sink = None
-    if world > 1:                                                      # bucketed gradient all-reduce overlapped with the backward
-        from emdr2_amd.model import kernels as Kmod
-        from emdr2_amd.training import GradientBuckets
-        sink = Kmod.GRAD_SINK = GradientBuckets(model.parameters())
     indexer = None
     if args.reindex_rows_per_step > 0:
         from emdr2_amd.tasks.openqa.e2eqa.async_indexer import AsyncIndexBuilder
@@ -125,20 +122,15 @@ def setup(args, rank, world, index=None, topk=50):
             indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
         opt.zero_grad()
-        if sink is not None:
-            sink.begin_step()
         lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
         loss, stats = emdr2_loss(lm, tlp, one, bt["labels"], bt["mask"], eos_id=30523)
         loss.backward()
-        if sink is not None:
-            sink.finish()
-        else:
-            allreduce_gradients(model)
+        opt.finish()                                                      # waits for the bucket all-reduces launched from inside the backward
         opt.step(lr=sched.get_lr())
         sched.step()
         return loss
 
-    return types.SimpleNamespace(step=step, model=model, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
@@ -182,7 +174,9 @@ def run(ctx, steps, warmup, world):
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
                    "dropout": ctx.dropout, "activation_recompute": "per layer", "loss": float(loss.detach()),
-                   "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1)},
+                   "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                   "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
+                   "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
         # dominant kernels of the step: the dense linears (NT GEMM forward / input gradients, TN GEMM weight gradients)
         "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_PEAK_TFLOPS, "traffic": None,
                      "kernel": "gemm_nt (gemm8_kernel / gemm_nt_kernel) + gemm_tn_kernel: executed flops / summed per-launch hipEvent time (rank 0)",

@@ -69,6 +69,9 @@ SIGNATURES.update({
     "emdr2_lse_gather_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "emdr2_sumsq_f32": (_i32, [_vp, _i64, _vp, _vp, _vp]),
     "emdr2_adam_step": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp]),
+    "emdr2_adam_step_flat": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i64, _f32, _f32, _f32, _f32, _f32, _i32, _vp, _f32, _vp]),
+    "emdr2_scale_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _f32, _vp]),
+    "emdr2_widen_bf16_to_f32": (_i32, [_vp, _vp, _i64, _vp]),
     "emdr2_cast_f32_to_bf16": (_i32, [_vp, _vp, _i64, _vp]),
     "emdr2_accum_bf16_to_f32": (_i32, [_vp, _vp, _i64, _f32, _vp]),
 })

@@ -668,6 +668,52 @@ __global__ void __launch_bounds__(256) adam_kernel(float *master, const float *g
     if (param_bf16) param_bf16[i] = f2bf(w);
 }
 
+// Adam over one FLAT bucket (all tensors of the bucket back to back; n % 4 == 0 by construction of the buckets): four elements per thread,
+// 16-byte accesses.  Elements [0, split) take the decoupled weight decay, [split, n) none (LayerNorm parameters and biases,
+// megatron/model/utils.py:64-83): the bucket stores its decayed parameters first, so one launch covers both groups.
+__global__ void __launch_bounds__(256) adam_flat_kernel(float4 *master, const float4 *grad, float4 *m, float4 *v, uint2 *work_bf16, long long n4,
+                                                        long long split4, float lr, float b1, float b2, float eps, float wd, float bc1, float bc2,
+                                                        const float *gnorm_sq, float clip)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    float scale = 1.f;
+    if (gnorm_sq && clip > 0.f) { const float gn = sqrtf(*gnorm_sq); const float c = clip / (gn + 1.0e-6f); if (c < 1.f) scale = c; }
+    const float wdi = i < split4 ? wd : 0.f;
+    const float4 g4 = grad[i], m4 = m[i], v4 = v[i], w4 = master[i];
+    float g[4] = {g4.x, g4.y, g4.z, g4.w}, mm[4] = {m4.x, m4.y, m4.z, m4.w}, vv[4] = {v4.x, v4.y, v4.z, v4.w}, w[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const float gj = g[j] * scale;
+        mm[j] = b1 * mm[j] + (1.f - b1) * gj;
+        vv[j] = b2 * vv[j] + (1.f - b2) * gj * gj;
+        const float upd = (mm[j] / bc1) / (sqrtf(vv[j] / bc2) + eps) + wdi * w[j];
+        w[j] = w[j] - lr * upd;
+    }
+    m[i] = make_float4(mm[0], mm[1], mm[2], mm[3]);
+    v[i] = make_float4(vv[0], vv[1], vv[2], vv[3]);
+    master[i] = make_float4(w[0], w[1], w[2], w[3]);
+    if (work_bf16) work_bf16[i] = make_uint2((uint32_t)f2bf(w[0]) | ((uint32_t)f2bf(w[1]) << 16), (uint32_t)f2bf(w[2]) | ((uint32_t)f2bf(w[3]) << 16));
+}
+
+// gradient exchange in bf16 (the reference all-reduces fp16 gradients pre-divided by the world size, model/distributed.py:53-62):
+// dst_bf16 = bf16(scale * src), and the way back dst_f32 = float(src_bf16); n % 4 == 0
+__global__ void __launch_bounds__(256) scale_cast_kernel(const float4 *src, uint2 *dst, long long n4, float scale)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const float4 x = src[i];
+    dst[i] = make_uint2((uint32_t)f2bf(x.x * scale) | ((uint32_t)f2bf(x.y * scale) << 16), (uint32_t)f2bf(x.z * scale) | ((uint32_t)f2bf(x.w * scale) << 16));
+}
+
+__global__ void __launch_bounds__(256) widen_kernel(const uint2 *src, float4 *dst, long long n4)
+{
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n4) return;
+    const uint2 x = src[i];
+    dst[i] = make_float4(bf2f((uint16_t)(x.x & 0xffff)), bf2f((uint16_t)(x.x >> 16)), bf2f((uint16_t)(x.y & 0xffff)), bf2f((uint16_t)(x.y >> 16)));
+}
+
 __global__ void __launch_bounds__(256) cast_kernel(const float *src, uint16_t *dst, long long n)
 {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -877,6 +923,35 @@ extern "C" int emdr2_adam_step(float *master, const float *grad, float *m, float
     const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
     hipLaunchKernelGGL(adam_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, master, grad, m, v, (uint16_t *)param_bf16,
                        (long long)n, lr, beta1, beta2, eps, weight_decay, bc1, bc2, gnorm_sq, clip);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_adam_step_flat(float *master, const float *grad, float *m, float *v, void *work_bf16, int64_t n, int64_t decay_split, float lr,
+                                    float beta1, float beta2, float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream)
+{
+    if (!master || !grad || !m || !v || n < 4 || (n & 3) || (decay_split & 3) || decay_split < 0 || decay_split > n || step < 1) return -1;
+    if (((uintptr_t)master | (uintptr_t)grad | (uintptr_t)m | (uintptr_t)v) & 15 || ((uintptr_t)work_bf16 & 7)) return -1;
+    const float bc1 = 1.f - powf(beta1, (float)step), bc2 = 1.f - powf(beta2, (float)step);
+    const long long n4 = n / 4;
+    hipLaunchKernelGGL(adam_flat_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (float4 *)master, (const float4 *)grad,
+                       (float4 *)m, (float4 *)v, (uint2 *)work_bf16, n4, (long long)(decay_split / 4), lr, beta1, beta2, eps, weight_decay, bc1, bc2,
+                       gnorm_sq, clip);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_scale_cast_f32_to_bf16(const float *src, void *dst, int64_t n, float scale, void *stream)
+{
+    if (!src || !dst || n < 4 || (n & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 7)) return -1;
+    hipLaunchKernelGGL(scale_cast_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (uint2 *)dst,
+                       (long long)(n / 4), scale);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_widen_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream)
+{
+    if (!src || !dst || n < 4 || (n & 3) || ((uintptr_t)dst & 15) || ((uintptr_t)src & 7)) return -1;
+    hipLaunchKernelGGL(widen_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint2 *)src, (float4 *)dst,
+                       (long long)(n / 4));
     return LAUNCH_OK();
 }
 

@@ -124,6 +124,7 @@ class _WeightCache(object):
 
     def __init__(self):
         self.epoch = 0
+        self.listeners = []       # called by invalidate(): training.FlatAdam keeps its own bf16 copies current (weakly held would be nicer; one per run)
 
     def get(self, p, kind, build):
         cache = p.__dict__.setdefault("_emdr2_cache", {})
@@ -137,12 +138,21 @@ class _WeightCache(object):
 
     def invalidate(self):
         self.epoch += 1
+        for ref in list(self.listeners):                          # weak references to bound methods
+            fn = ref()
+            if fn is None:
+                self.listeners.remove(ref)
+            else:
+                fn()
 
 
 WEIGHTS = _WeightCache()
 
 
 def w_bf16(p):
+    flat = p.__dict__.get("_emdr2_flat")
+    if flat is not None:                      # the parameter lives in a training.FlatAdam bucket: its bf16 copy is a view the Adam kernel writes
+        return flat.work_view(p)
     return WEIGHTS.get(p, "bf16", lambda: cast_bf16(p.detach().contiguous()))
 
 

@@ -41,12 +41,12 @@ def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler,
     from emdr2_amd.model import kernels
     optimizer.zero_grad()
     sink = kernels.GRAD_SINK
-    if sink is not None:
+    if sink is not None and sink is not optimizer:
         sink.begin_step()
     loss, loss_reduced = forward_step_func(data_iterator, model, eos_id)
     loss.backward()
     if sink is not None:
-        sink.finish()                                # buckets were all-reduced while the backward ran
+        sink.finish()                                # buckets were all-reduced (bf16, pre-divided) while the backward ran
     else:
         allreduce_gradients(model, dp_group)
     # the reference steps the optimizer with the rate its scheduler set at the END of the previous iteration (training.py:223-228,
@@ -152,7 +152,11 @@ def setup_model_and_optimizer(model_provider):
     """megatron/training.py:136-162: model, FusedAdam over the (decay / no-decay) groups, AnnealingLR, resume or pre-trained init."""
     args = get_args()
     model = model_provider()
-    optimizer = FusedAdam(get_params_for_weight_decay_optimization(model), lr=args.lr, weight_decay=args.weight_decay, clip_grad=args.clip_grad)
+    from emdr2_amd.model import kernels
+    from emdr2_amd.training import FlatAdam
+    # flat buckets (masters, gradients, moments, bf16 working copies), no-decay grouping of model/utils.py:64-83 inside each bucket; it is
+    # also the gradient sink of the backward: data-parallel buckets are exchanged in bf16 as soon as they are complete
+    optimizer = kernels.GRAD_SINK = FlatAdam(model, lr=args.lr, weight_decay=args.weight_decay, clip_grad=args.clip_grad)
     num_iters = args.lr_decay_iters if args.lr_decay_iters is not None else args.train_iters
     num_iters = max(1, num_iters)
     lr_scheduler = AnnealingLR(args.lr, warmup_iter=args.warmup * num_iters, total_iters=num_iters, min_lr=args.min_lr)
@@ -239,10 +243,6 @@ def train(train_valid_datasets_provider, model_provider, forward_step=_cross_ent
     if args.epochs > 0 and end_of_epoch_callback_provider is not None:
         cb1, cb2 = end_of_epoch_callback_provider(args.valid_data), end_of_epoch_callback_provider(args.test_data)
     model, optimizer, lr_scheduler = setup_model_and_optimizer(model_provider)
-    if _dp()[1] > 1:                                                                         # overlap the gradient all-reduce with the backward
-        from emdr2_amd.model import kernels
-        from emdr2_amd.training import GradientBuckets
-        kernels.GRAD_SINK = GradientBuckets(model.parameters())
     if args.iteration == 0 and args.pretrained_checkpoint is not None:                     # train_e2eqa.py:586-593: weights only
         checkpointing.load_checkpoint(args.pretrained_checkpoint, model, None, None)
     print_rank_0('done with setups ...')

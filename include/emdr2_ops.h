@@ -114,6 +114,15 @@ int emdr2_lse_gather_bwd(const void *logits, const int64_t *labels, const float 
 int emdr2_sumsq_f32(const float *g, int64_t n, float *out, float *scratch, void *stream);
 int emdr2_adam_step(float *master, const float *grad, float *m, float *v, void *param_bf16, int64_t n, float lr, float beta1, float beta2,
                     float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream);
+/* The same update over one FLAT bucket of parameters (masters, gradients, both moments and the bf16 working copies of many tensors stored back
+ * to back; apex runs FusedAdam through amp_C.multi_tensor_apply for the same reason, fp16/fp16.py:420-474): elements [0, decay_split) take
+ * the weight decay, the rest none.  n, decay_split multiples of 4; fp32 buffers 16-byte aligned. */
+int emdr2_adam_step_flat(float *master, const float *grad, float *m, float *v, void *work_bf16, int64_t n, int64_t decay_split, float lr,
+                         float beta1, float beta2, float eps, float weight_decay, int step, const float *gnorm_sq, float clip, void *stream);
+/* Gradient exchange in 16 bits (the reference all-reduces fp16 gradients pre-divided by the world size, model/distributed.py:53-62):
+ * dst = bf16(scale * src) before the all-reduce, dst = float(src) after it.  n % 4 == 0. */
+int emdr2_scale_cast_f32_to_bf16(const float *src, void *dst, int64_t n, float scale, void *stream);
+int emdr2_widen_bf16_to_f32(const void *src, float *dst, int64_t n, void *stream);
 int emdr2_cast_f32_to_bf16(const float *src, void *dst, int64_t n, void *stream);
 int emdr2_accum_bf16_to_f32(const void *src, float *dst, int64_t n, float scale, void *stream);
 

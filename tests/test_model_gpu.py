@@ -319,3 +319,52 @@ def test_gradient_buckets_do_not_change_single_process_training():
     assert set(grads[0]) == set(grads[1])
     for k in grads[0]:
         assert _rel(grads[1][k], grads[0][k]) < 1e-3, k                  # fp32 atomics reorder sums between runs
+
+
+@pytest.mark.parametrize("clip", [0.0, 1.0])
+def test_flat_adam_matches_per_parameter_adam_with_few_launches(clip):
+    """training.FlatAdam (flat buckets: one sum-of-squares + one Adam launch per bucket, decay split inside the bucket, bf16 working copies
+    written by the Adam kernel) against the per-parameter FusedAdam on the same gradients: masters bit-identical after three steps without clipping (with clipping the
+    global norm is summed over buckets instead of tensors: equal to fp32 round-off), the
+    never-used token-type table untouched, <= 30 optimizer launches per step, working copies current."""
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.model.transformer import Config, T5Model
+    from emdr2_amd.training import FlatAdam, FusedAdam, get_params_for_weight_decay_optimization
+    rng = np.random.default_rng(12)
+    enc_ids, dec_ids = _ids(rng, (8, 64), 512).cuda(), _ids(rng, (8, 32), 512).cuda()
+    results = []
+    for flat in (False, True):
+        torch.manual_seed(0)
+        K.DROPOUT._sites = 0
+        cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05)
+        m = T5Model(cfg, 512, checkpoint_activations=True).train()
+        tt0 = m.language_model.embedding.tokentype_embeddings.weight.detach().clone()
+        if flat:
+            opt = K.GRAD_SINK = FlatAdam(m, lr=1e-2, weight_decay=0.1, clip_grad=clip, bucket_bytes=1 << 20)
+            assert len(opt.buckets) >= 2
+        else:
+            opt = FusedAdam(get_params_for_weight_decay_optimization(m), lr=1e-2, weight_decay=0.1, clip_grad=clip)
+        try:
+            for step in range(3):
+                opt.zero_grad()
+                logits, _ = m(enc_ids, dec_ids)
+                logits.float().square().mean().backward()
+                if flat:
+                    opt.finish()
+                    w = m.language_model.embedding.word_embeddings.weight          # tied: encoder + decoder embedding + LM head
+                    assert opt.expected[w] == 3 and w.grad.data_ptr() == opt.grad_view(w).data_ptr()
+                opt.step()
+            if flat:
+                assert opt.optimizer_launches <= 30, opt.optimizer_launches
+                for p in m.parameters():                                            # what the next GEMM would read == bf16(master)
+                    assert torch.equal(K.w_bf16(p), p.detach().bfloat16())
+        finally:
+            K.GRAD_SINK = None
+        assert torch.equal(m.language_model.embedding.tokentype_embeddings.weight, tt0)
+        results.append({k: p.detach().clone() for k, p in m.named_parameters()})
+    assert set(results[0]) == set(results[1])
+    for k in results[0]:
+        if clip == 0.0:
+            assert torch.equal(results[0][k], results[1][k]), k
+        else:
+            assert torch.allclose(results[0][k], results[1][k], rtol=1e-5, atol=1e-7), k
