@@ -1,6 +1,7 @@
 """GPU, world size 2 on ONE device (gloo transport, both ranks on cuda:0): the multi-rank search path with the real HIP kernels --
 per-rank shard scan, all-gather of the per-shard top-k, HIP merge kernel -- must equal the single-shard oracle on every rank, for the
-canonical fp16 search and for the FaissMIPSIndex fp32-score search.  (RCCL itself is exercised only by the driver's multi-GPU runs.)"""
+canonical fp16 search and for the FaissMIPSIndex fp32-score search.  The same two workers also run over RCCL ("nccl" backend, one GPU
+per rank) whenever the box has two GPUs -- the first contact with RCCL is then a test, not the driver's 8-GPU benchmark."""
 import os
 import socket
 import sys
@@ -12,13 +13,22 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port):
+def _init(rank, world, port, backend):
+    """gloo: both ranks share cuda:0 (CPU transport).  nccl (= RCCL): one GPU per rank."""
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    import torch
+    dev = rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    extra = {"device_id": torch.device("cuda", dev)} if backend == "nccl" else {}
+    torch.distributed.init_process_group(backend, rank=rank, world_size=world, **extra)
+
+
+def _worker(rank, world, port, backend="gloo"):
+    _init(rank, world, port, backend)
     import numpy as np
     import torch
-    torch.cuda.set_device(0)
-    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, FaissMIPSIndex
     from oracle import mips_oracle as mo
     rng = np.random.default_rng(0)
@@ -47,13 +57,10 @@ def test_two_rank_sharded_search_equals_single_shard_oracle():
     mp.spawn(_worker, args=(2, port), nprocs=2, join=True)
 
 
-def _train_worker(rank, world, port, out_dir):
-    sys.path.insert(0, ROOT)
-    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+def _train_worker(rank, world, port, out_dir, backend="gloo"):
+    _init(rank, world, port, backend)
     import numpy as np
     import torch
-    torch.cuda.set_device(0)
-    torch.distributed.init_process_group("gloo", rank=rank, world_size=world)
     from emdr2_amd.model import kernels as K
     from emdr2_amd.model.transformer import Config, T5Model
     from emdr2_amd.training import FlatAdam
@@ -86,5 +93,27 @@ def test_two_rank_data_parallel_training_keeps_replicas_identical(tmp_path):
     mp.spawn(_train_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     p0, p1 = torch.load(os.path.join(str(tmp_path), "p0.pt")), torch.load(os.path.join(str(tmp_path), "p1.pt"))
     assert len(p0) == len(p1) > 10
+    for a, b in zip(p0, p1):
+        assert torch.equal(a, b)
+
+
+def _two_gpus():
+    import torch
+    return torch.cuda.is_available() and torch.cuda.device_count() >= 2
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs (RCCL)")
+def test_two_rank_sharded_search_over_rccl():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_worker, args=(2, port, "nccl"), nprocs=2, join=True)
+
+
+@pytest.mark.skipif(not _two_gpus(), reason="needs two GPUs (RCCL)")
+def test_two_rank_data_parallel_training_over_rccl(tmp_path):
+    """bf16 bucket all-reduce on the communicator's stream overlapped with the backward, on real xGMI links: replicas bit-identical."""
+    import torch
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_train_worker, args=(2, port, str(tmp_path), "nccl"), nprocs=2, join=True)
+    p0, p1 = torch.load(os.path.join(str(tmp_path), "p0.pt")), torch.load(os.path.join(str(tmp_path), "p1.pt"))
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
