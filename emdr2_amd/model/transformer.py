@@ -117,6 +117,19 @@ class ParallelAttention(torch.nn.Module):
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
 
+    def step_self(self, x1, ids_cur, ids_block, pos, cache, residual):
+        """One decoding step of SELF-attention with a K/V cache (the reference's `layer_past` / `get_key_value` plumbing,
+        transformer.py:273-280,321-332): x1 [b, 1, h] is the hidden state at position `pos`; its K and V are written into
+        cache [b, Lc, 2, np, hn] and the query attends to the whole cache -- positions behind `pos` hold token id 0 in `ids_block` [b, Lc]
+        and are masked like padding, which IS the history mask for the newest position."""
+        b = x1.shape[0]
+        mixed = K.linear(x1, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(b, 1, 3, self.heads, self.hn)
+        cache[:, pos, 0] = mixed[:, 0, 1]
+        cache[:, pos, 1] = mixed[:, 0, 2]
+        ctx = K.attention_core(mixed[:, :, 0], cache, ids_cur, ids_block, False).view(b, 1, self.heads * self.hn)
+        return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual)
+
+
 class ParallelTransformerLayer(torch.nn.Module):
     def __init__(self, cfg, out_std, layer_type="encoder"):
         super().__init__()
@@ -137,6 +150,17 @@ class ParallelTransformerLayer(torch.nn.Module):
         if self.layer_type == "decoder":
             x = self.inter_attention(ln, ids, enc_ids, False, residual=x, encoder_output=encoder_output)
             ln, x = self.post_inter_attention_layernorm(x, with_residual=True)
+        return self.mlp(ln, residual=x)
+
+
+    def step(self, x1, ids_cur, ids_block, pos, cache, encoder_output, enc_ids):
+        """Decoder layer for ONE new position (no-grad decoding): cached self-attention, cross-attention over the cached K/V projection of
+        the encoder output (`cross_kv_cache`), MLP."""
+        ln, x = self.input_layernorm(x1, with_residual=True)
+        x = self.self_attention.step_self(ln, ids_cur, ids_block, pos, cache, residual=x)
+        ln, x = self.post_attention_layernorm(x, with_residual=True)
+        x = self.inter_attention(ln, ids_cur, enc_ids, False, residual=x, encoder_output=encoder_output)
+        ln, x = self.post_inter_attention_layernorm(x, with_residual=True)
         return self.mlp(ln, residual=x)
 
 
@@ -212,6 +236,27 @@ class TransformerLanguageModel(torch.nn.Module):
     def decode(self, dec_ids, encoder_output, enc_ids):
         return self.decoder(self.embedding(dec_ids), dec_ids, causal=True, encoder_output=encoder_output, enc_ids=enc_ids)
 
+    # ---- incremental decoding (search_strategy.py:185-240 re-decodes the whole prefix for every token) --------------------
+    def init_decode_state(self, batch, max_len, device="cuda"):
+        """Per-layer self-attention K/V cache [b, Lc, 2, np, hn] (Lc = max_len rounded up to 32: the P V product wants K % 32 == 0)."""
+        lc = (max_len + 31) // 32 * 32
+        att = self.decoder.layers[0].self_attention
+        return {"len": lc, "kv": [torch.zeros((batch, lc, 2, att.heads, att.hn), dtype=torch.bfloat16, device=device) for _ in self.decoder.layers]}
+
+    def decode_step(self, ids_cur, pos, ids_block, encoder_output, enc_ids, state):
+        """Hidden state [b, 1, h] of position `pos` given the tokens so far: ids_cur [b, 1] = ids_block[:, pos]; ids_block [b, Lc] holds the
+        prefix and zeros behind it.  Use inside `cross_kv_cache` so the encoder K/V are projected once."""
+        emb = self.embedding
+        b = ids_cur.shape[0]
+        h = emb.word_embeddings.weight.shape[1]
+        x = torch.empty((b, 1, h), dtype=torch.bfloat16, device=ids_cur.device)
+        pos_row = K.w_bf16(emb.position_embeddings.weight)[pos:pos + 1]          # the table row of THIS position (the kernel indexes by s % S, S = 1)
+        K._native.check(K._lib().emdr2_embedding_fwd(ids_cur.contiguous().data_ptr(), None, K.w_bf16(emb.word_embeddings.weight).data_ptr(),
+                                                     pos_row.data_ptr(), None, x.data_ptr(), b, 1, h, 0.0, 0, K._sp()), "embedding_fwd")
+        for layer, cache in zip(self.decoder.layers, state["kv"]):
+            x = layer.step(x, ids_cur, ids_block, pos, cache, encoder_output, enc_ids)
+        return self.decoder.final_layernorm(x)
+
 
 class cross_kv_cache(object):
     """Context manager: inside it (no_grad, eval) every decoder cross-attention keeps the K/V projection of the encoder output it saw
@@ -279,6 +324,11 @@ class T5Model(torch.nn.Module):
 
     def decode(self, decoder_input_ids, enc_hidden_states, enc_ids):
         dec = self.decode_hidden(decoder_input_ids, enc_hidden_states, enc_ids)
+        return self.lm_head(dec, self.language_model.embedding.word_embeddings.weight)
+
+    def decode_step(self, ids_cur, pos, ids_block, enc_hidden_states, enc_ids, state):
+        """LM logits [b, 1, V] of the next token after position `pos` (incremental decoding with K/V caches)."""
+        dec = self.language_model.decode_step(ids_cur, pos, ids_block, enc_hidden_states, enc_ids, state)
         return self.lm_head(dec, self.language_model.embedding.word_embeddings.weight)
 
     def forward(self, encoder_input_ids, decoder_input_ids):

@@ -234,3 +234,35 @@ def random_params(cfg, bert_vocab, t5_vocab, max_pos=512, std=0.02, seed=1234):
     lm("language_model.language_model", t5_vocab, True)
     P["language_model.lm_head.bias"] = torch.zeros(t5_vocab)
     return P
+
+
+# ---- greedy answer generation (megatron/model/search_strategy.py:185-240, SampleOrGreedySearch with sample=False) ------------------------------
+def greedy_decode(P, cfg, qext_ids, K, max_decode_len, bos_id, eos_id, return_margins=False):
+    """Encode the K retrieved passages of every question once (EMDR2Model.forward, eval mode, emdr2_model.py:148-183), then decode token by
+    token: each step re-runs the decoder on the whole prefix and takes the arg-max of the last position; stops when every question has
+    produced [EOS]; answers are cut at their first [EOS], an empty answer becomes [1].  qext_ids [B*K, S]."""
+    B = qext_ids.shape[0] // K
+    H = cfg["hidden"]
+    with torch.no_grad():
+        enc = t5_encode(P, "language_model", cfg, qext_ids, ~make_attention_mask_3d(qext_ids, qext_ids)).reshape(B, -1, H)
+        unflat = qext_ids.reshape(B, -1)
+        y = torch.full((B, 1), bos_id, dtype=torch.int64)
+        eos = torch.zeros(B, dtype=torch.int64)
+        steps, margins = [], []
+        for _ in range(max_decode_len):
+            d_mask = ~(make_attention_mask_3d(y, y) * make_history_mask_3d(y))
+            logits = t5_decode(P, "language_model", cfg, y, enc, d_mask, ~make_attention_mask_3d(y, unflat))[:, -1, :].float()
+            top2 = torch.topk(logits, 2, dim=1)
+            ys = top2.indices[:, 0]
+            margins.append(top2.values[:, 0] - top2.values[:, 1])
+            y = torch.cat([y, ys[:, None]], dim=1)
+            steps.append(ys)
+            eos += (ys == eos_id).long()
+            if bool((eos > 0).all()):
+                break
+    out = []
+    for row in torch.stack(steps, 1).tolist():
+        if eos_id in row:
+            row = row[:row.index(eos_id)]
+        out.append(row if row else [1])
+    return (out, torch.stack(margins, 1)) if return_margins else out

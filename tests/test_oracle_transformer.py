@@ -112,3 +112,34 @@ def test_base_size_layer_fixture_from_the_reference():
             check(kind + ".denc", enc.grad)
         for k in lb.layer_params(kind, seed):
             check(kind + ".grad." + k, P["L." + k].grad, tol=5e-4)
+
+
+def _sharpen(name, w, gain):
+    """The transformation tests/golden/gen_decode_golden.py applies to the stored toy weights (see there)."""
+    if not name.startswith("language_model."):
+        return w
+    if name.endswith("lm_head.bias"):
+        return torch.zeros_like(w)
+    if name.endswith(".weight") and w.dim() == 2 and "layernorm" not in name and "embedding" not in name:
+        return w * gain
+    return w
+
+
+def test_greedy_decode_matches_the_reference_search_strategy():
+    """f4: the oracle's greedy decoder against the ids the reference's own SampleOrGreedySearch produced (search_strategy.py:185-240) on
+    the toy model with an injected retriever (tests/golden/decode_ref.npz): identical token ids for all 16 questions."""
+    import os
+    import assembly_cases
+    from oracle import assembly_oracle as ao
+    g, P, _, meta, passages, titles = mf.load()
+    d = np.load(os.path.join(os.path.dirname(__file__), "golden", "decode_ref.npz"))
+    P = {k: _sharpen(k, v, float(d["reader_gain"])) for k, v in P.items()}
+    corpus = ao.Corpus(passages, titles, assembly_cases.build()["group_of_doc"])
+    _, _, ext, _, _ = ao.postprocess(d["query_uid"].tolist(), d["query_ids"].tolist(), d["query_len"].tolist(), d["topk_ids"].tolist(), corpus,
+                                     mf.CFG["topk"], mf.CFG["seq_ret"], mf.CFG["seq"], meta["cls"], meta["sep"], meta["pad"])
+    outs, margins = to.greedy_decode(P, mf.CFG, torch.tensor(ext, dtype=torch.int64), mf.CFG["topk"], int(d["max_decode_len"]), int(d["bos"]),
+                                     int(d["eos"]), return_margins=True)
+    ref = [[t for t in row if t >= 0] for row in d["decoded"].tolist()]
+    assert outs == ref
+    assert len(set(map(tuple, ref))) >= 8                                # the fixture depends on the evidence, it is not one constant answer
+    np.testing.assert_allclose(margins.numpy(), d["margins"], rtol=2e-2, atol=2e-4)
