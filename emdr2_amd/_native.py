@@ -78,6 +78,10 @@ SIGNATURES.update({
 
 
 SIGNATURES["emdr2_gemm_nt_lse_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
+SIGNATURES["emdr2_retriever_prior_fwd"] = (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])
+SIGNATURES["emdr2_retriever_prior_bwd"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])
+SIGNATURES["emdr2_marginal_fwd"] = (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp])
+SIGNATURES["emdr2_marginal_bwd"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp])
 SIGNATURES["emdr2_lse_combine"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp])
 SIGNATURES["emdr2_ops_set_timing"] = (_i32, [_i32])
 SIGNATURES["emdr2_ops_timing_collect"] = (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), _i32])

@@ -860,6 +860,96 @@ extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, int cols, floa
     return LAUNCH_OK();
 }
 
+// ---- retriever prior (emdr2_model.py:134-145): sim[b, k] = <q[b], c[b, k]> * scale, log-softmax over the K retrieved passages --------------------
+// One workgroup per question; K <= 128 (top-k 50 / 100 + 1).  q, c bf16, everything else fp32.  prob (= exp(logp)) is kept for the backward.
+__global__ void __launch_bounds__(256) retriever_prior_fwd_kernel(const uint16_t *q, const uint16_t *c, float *logp, float *prob, int K, int H, float scale)
+{
+    __shared__ float sim[128];
+    __shared__ float stat[2];
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const uint16_t *qb = q + (long long)b * H;
+    for (int k = wave; k < K; k += 4) {
+        const uint16_t *ck = c + ((long long)b * K + k) * H;
+        float s = 0.f;
+        for (int i = lane * 8; i < H; i += 512) {
+            const uint4 qa = *(const uint4 *)(qb + i), ca = *(const uint4 *)(ck + i);
+            const uint32_t qw[4] = {qa.x, qa.y, qa.z, qa.w}, cw[4] = {ca.x, ca.y, ca.z, ca.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                s += bf2f((uint16_t)(qw[j] & 0xffff)) * bf2f((uint16_t)(cw[j] & 0xffff)) + bf2f((uint16_t)(qw[j] >> 16)) * bf2f((uint16_t)(cw[j] >> 16));
+        }
+        s = wave_sum(s);
+        if (lane == 0) sim[k] = s * scale;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float a = lane < K ? sim[lane] : -3.0e38f, a2 = lane + 64 < K ? sim[lane + 64] : -3.0e38f;
+        const float m = wave_max(fmaxf(a, a2));
+        const float e = (lane < K ? __expf(a - m) : 0.f) + (lane + 64 < K ? __expf(a2 - m) : 0.f);
+        const float l = wave_sum(e);
+        if (lane == 0) { stat[0] = m; stat[1] = __logf(l); }
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float lp = sim[k] - stat[0] - stat[1];
+        logp[(long long)b * K + k] = lp;
+        prob[(long long)b * K + k] = __expf(lp);
+    }
+}
+
+// d sim[k] = (g[k] - prob[k] * sum_j g[j]) * scale;  dq[h] = sum_k dsim[k] c[k, h];  dc[k, h] = dsim[k] q[h]   (bf16 gradients out)
+__global__ void __launch_bounds__(256) retriever_prior_bwd_kernel(const float *g, const float *prob, const uint16_t *q, const uint16_t *c, uint16_t *dq,
+                                                                  uint16_t *dc, int K, int H, float scale)
+{
+    __shared__ float dsim[128];
+    __shared__ float gsum;
+    const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float *gb = g + (long long)b * K, *pb = prob + (long long)b * K;
+    if (wave == 0) {
+        const float t = wave_sum((lane < K ? gb[lane] : 0.f) + (lane + 64 < K ? gb[lane + 64] : 0.f));
+        if (lane == 0) gsum = t;
+    }
+    __syncthreads();
+    for (int k = threadIdx.x; k < K; k += 256) dsim[k] = (gb[k] - pb[k] * gsum) * scale;
+    __syncthreads();
+    const uint16_t *qb = q + (long long)b * H, *cb = c + (long long)b * K * H;
+    for (int h = threadIdx.x; h < H; h += 256) {
+        float acc = 0.f;
+        const float qh = bf2f(qb[h]);
+        for (int k = 0; k < K; ++k) {
+            acc += dsim[k] * bf2f(cb[(long long)k * H + h]);
+            if (dc) dc[((long long)b * K + k) * H + h] = f2bf(dsim[k] * qh);
+        }
+        if (dq) dq[(long long)b * H + h] = f2bf(acc);
+    }
+}
+
+// ---- EMDR2 marginal (train_e2eqa.py:98-123): marginal[b, l] = logsumexp_k( prior[b, k] + gold[b, k, l] ) -------------------------------------------
+__global__ void __launch_bounds__(64) marginal_fwd_kernel(const float *prior, const float *gold, float *marginal, int K, int L)
+{
+    const int b = blockIdx.x;
+    for (int l = threadIdx.x; l < L; l += 64) {
+        float m = -3.0e38f;
+        for (int k = 0; k < K; ++k) m = fmaxf(m, prior[(long long)b * K + k] + gold[((long long)b * K + k) * L + l]);
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += __expf(prior[(long long)b * K + k] + gold[((long long)b * K + k) * L + l] - m);
+        marginal[(long long)b * L + l] = m + __logf(s);
+    }
+}
+
+// d prior[b, k] = sum_l gm[b, l] * exp(prior[b, k] + gold[b, k, l] - marginal[b, l])      (gold is a constant of the loss: no-grad pass)
+__global__ void __launch_bounds__(128) marginal_bwd_kernel(const float *prior, const float *gold, const float *marginal, const float *gm, float *dprior,
+                                                           int K, int L)
+{
+    const int b = blockIdx.x;
+    for (int k = threadIdx.x; k < K; k += 128) {
+        const float pk = prior[(long long)b * K + k];
+        float acc = 0.f;
+        for (int l = 0; l < L; ++l) acc += gm[(long long)b * L + l] * __expf(pk + gold[((long long)b * K + k) * L + l] - marginal[(long long)b * L + l]);
+        dprior[(long long)b * K + k] = acc;
+    }
+}
+
 // out[row] = gold[row] - logsumexp over the row's partials (max_j, sum_j exp(x - max_j)) written by emdr2_gemm_nt_lse_bf16: one wave per row
 __global__ void __launch_bounds__(256) lse_combine_kernel(const float *pmax, const float *psum, const float *gold, float *out, float *lse,
                                                            long long rows, int slots)
@@ -879,6 +969,38 @@ __global__ void __launch_bounds__(256) lse_combine_kernel(const float *pmax, con
         if (lse) lse[row] = l;
         out[row] = gold[row] - l;
     }
+}
+
+extern "C" int emdr2_retriever_prior_fwd(const void *q, const void *c, float *logp, float *prob, int batch, int K, int H, float scale, void *stream)
+{
+    if (!q || !c || !logp || !prob || batch < 1 || K < 1 || K > 128 || H < 8 || (H & 7) || ((uintptr_t)q & 15) || ((uintptr_t)c & 15)) return -1;
+    hipLaunchKernelGGL(retriever_prior_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)q, (const uint16_t *)c, logp, prob, K,
+                       H, scale);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_retriever_prior_bwd(const float *dlogp, const float *prob, const void *q, const void *c, void *dq, void *dc, int batch, int K, int H,
+                                         float scale, void *stream)
+{
+    if (!dlogp || !prob || !q || !c || (!dq && !dc) || batch < 1 || K < 1 || K > 128 || H < 8) return -1;
+    hipLaunchKernelGGL(retriever_prior_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dlogp, prob, (const uint16_t *)q, (const uint16_t *)c,
+                       (uint16_t *)dq, (uint16_t *)dc, K, H, scale);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_marginal_fwd(const float *prior, const float *gold, float *marginal, int batch, int K, int L, void *stream)
+{
+    if (!prior || !gold || !marginal || batch < 1 || K < 1 || L < 1) return -1;
+    hipLaunchKernelGGL(marginal_fwd_kernel, dim3(batch), dim3(64), 0, (hipStream_t)stream, prior, gold, marginal, K, L);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_marginal_bwd(const float *prior, const float *gold, const float *marginal, const float *dmarginal, float *dprior, int batch, int K,
+                                  int L, void *stream)
+{
+    if (!prior || !gold || !marginal || !dmarginal || !dprior || batch < 1 || K < 1 || L < 1) return -1;
+    hipLaunchKernelGGL(marginal_bwd_kernel, dim3(batch), dim3(128), 0, (hipStream_t)stream, prior, gold, marginal, dmarginal, dprior, K, L);
+    return LAUNCH_OK();
 }
 
 extern "C" int emdr2_lse_combine(const float *part_max, const float *part_sum, const float *gold, float *out, float *lse, int64_t rows, int slots,

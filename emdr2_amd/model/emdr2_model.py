@@ -207,11 +207,8 @@ class EMDR2Model(torch.nn.Module):
                                              self.disable_retriever_dropout).reshape(B, Kk, H)
         if self.no_context_embedder_training:
             ctx_logits = ctx_logits.detach()
-        # fresh retriever scores (emdr2_model.py:134-145): 2*B*K*H flop, negligible; kept in torch fp32 on purpose
-        sim = torch.bmm(query_logits.unsqueeze(1).float(), ctx_logits.float().transpose(1, 2))
-        if self.retriever_score_scaling:
-            sim = sim / math.sqrt(H)
-        topk_log_probs = torch.log_softmax(sim, dim=2).squeeze(1)
+        # fresh retriever scores -> prior over the K passages (emdr2_model.py:134-145): fp32 dot products, /sqrt(H), log-softmax, one HIP kernel
+        topk_log_probs = K.retriever_prior(query_logits, ctx_logits, 1.0 / math.sqrt(H) if self.retriever_score_scaling else 1.0)
 
         S = qext.shape[1]
         enc = self.language_model.encode(qext).reshape(B, Kk * S, H)                          # K passages concatenated (FiD), :148-164
@@ -288,7 +285,7 @@ def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_ma
             retriever_loss = torch.nn.functional.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='batchmean')
             stats["retriever_loss"] = retriever_loss.detach()
             return lm_loss + retriever_loss, stats
-        marginal = torch.logsumexp(topk_log_probs.float().unsqueeze(-1) + gold1, dim=1)
+        marginal = K.marginal_logsumexp(topk_log_probs, gold1)                                  # [B, L] = logsumexp_k(prior + gold), HIP kernel pair
         retriever_loss = -torch.sum(marginal * mask) / mask.sum()
         util_mask = mask.masked_fill(lab >= eos_id, 0)
         stats["retriever_utility"] = (torch.sum((marginal - gold1[:, -1, :]) * util_mask) / util_mask.sum()).detach()

@@ -578,3 +578,64 @@ def lm_head_gold_logprob(hidden, weight, bias, labels):
                                                 lab.data_ptr(), pmax.data_ptr(), psum.data_ptr(), gold.data_ptr(), _sp()), "gemm_nt_lse")
     _native.check(_lib().emdr2_lse_combine(pmax.data_ptr(), psum.data_ptr(), gold.data_ptr(), out.data_ptr(), None, M, slots, _sp()), "lse_combine")
     return out.reshape(labels.shape)
+
+
+class RetrieverPriorFn(torch.autograd.Function):
+    """topk_log_probs [B, K] = log_softmax_k(<q_b, c_bk> * scale) (emdr2_model.py:134-145) on the HIP kernel pair of elementwise.hip."""
+
+    @staticmethod
+    def forward(ctx, q, c, scale):
+        _check_bf16(q, c)
+        q, c = q.contiguous(), c.contiguous()
+        B, Kk, H = c.shape
+        logp = torch.empty((B, Kk), dtype=torch.float32, device=q.device)
+        prob = torch.empty_like(logp)
+        _native.check(_lib().emdr2_retriever_prior_fwd(q.data_ptr(), c.data_ptr(), logp.data_ptr(), prob.data_ptr(), B, Kk, H, float(scale), _sp()),
+                      "retriever_prior_fwd")
+        ctx.save_for_backward(q, c, prob)
+        ctx.scale = float(scale)
+        return logp
+
+    @staticmethod
+    def backward(ctx, dlogp):
+        q, c, prob = ctx.saved_tensors
+        B, Kk, H = c.shape
+        dq = torch.empty_like(q) if ctx.needs_input_grad[0] else None
+        dc = torch.empty_like(c) if ctx.needs_input_grad[1] else None
+        if dq is None and dc is None:
+            return None, None, None
+        g = dlogp.to(torch.float32).contiguous()
+        _native.check(_lib().emdr2_retriever_prior_bwd(g.data_ptr(), prob.data_ptr(), q.data_ptr(), c.data_ptr(), _ptr(dq), _ptr(dc), B, Kk, H, ctx.scale,
+                                                       _sp()), "retriever_prior_bwd")
+        return dq, dc, None
+
+
+def retriever_prior(q, c, scale):
+    return RetrieverPriorFn.apply(q, c, scale)
+
+
+class MarginalFn(torch.autograd.Function):
+    """marginal [B, L] = logsumexp_k(prior[b, k] + gold[b, k, l]) (train_e2eqa.py:98-123); gold comes from the no-grad pass (constant)."""
+
+    @staticmethod
+    def forward(ctx, prior, gold):
+        prior, gold = prior.to(torch.float32).contiguous(), gold.to(torch.float32).contiguous()
+        B, Kk, L = gold.shape
+        out = torch.empty((B, L), dtype=torch.float32, device=gold.device)
+        _native.check(_lib().emdr2_marginal_fwd(prior.data_ptr(), gold.data_ptr(), out.data_ptr(), B, Kk, L, _sp()), "marginal_fwd")
+        ctx.save_for_backward(prior, gold, out)
+        return out
+
+    @staticmethod
+    def backward(ctx, dm):
+        prior, gold, out = ctx.saved_tensors
+        B, Kk, L = gold.shape
+        dprior = torch.empty_like(prior)
+        dm = dm.to(torch.float32).contiguous()
+        _native.check(_lib().emdr2_marginal_bwd(prior.data_ptr(), gold.data_ptr(), out.data_ptr(), dm.data_ptr(), dprior.data_ptr(), B, Kk, L, _sp()),
+                      "marginal_bwd")
+        return dprior, None
+
+
+def marginal_logsumexp(prior, gold):
+    return MarginalFn.apply(prior, gold)

@@ -137,6 +137,18 @@ int emdr2_gemm_nt_lse_bf16(const void *A, int64_t lda, const void *B, int64_t ld
 int emdr2_lse_combine(const float *part_max, const float *part_sum, const float *gold, float *out, float *lse, int64_t rows, int slots,
                       void *stream);
 
+/* Retriever prior over the K retrieved passages (emdr2_model.py:134-145): logp[b, k] = log_softmax_k( <q[b], c[b, k]> * scale ), scale =
+ * 1/sqrt(H) with --retriever-score-scaling; q bf16 [batch, H], c bf16 [batch, K, H], logp / prob (= exp(logp), kept for the backward) fp32
+ * [batch, K]; K <= 128.  bwd: bf16 gradients dq [batch, H], dc [batch, K, H] (either may be NULL: --no-query/context-embedder-training). */
+int emdr2_retriever_prior_fwd(const void *q, const void *c, float *logp, float *prob, int batch, int K, int H, float scale, void *stream);
+int emdr2_retriever_prior_bwd(const float *dlogp, const float *prob, const void *q, const void *c, void *dq, void *dc, int batch, int K, int H,
+                              float scale, void *stream);
+/* EMDR2 marginal likelihood (train_e2eqa.py:98-123): marginal[b, l] = logsumexp_k( prior[b, k] + gold[b, k, l] ), gold = per-passage gold
+ * log-likelihoods of the no-grad one-context pass (constants).  bwd: dprior[b, k] = sum_l dmarginal[b, l] * posterior[b, k, l].  All fp32. */
+int emdr2_marginal_fwd(const float *prior, const float *gold, float *marginal, int batch, int K, int L, void *stream);
+int emdr2_marginal_bwd(const float *prior, const float *gold, const float *marginal, const float *dmarginal, float *dprior, int batch, int K, int L,
+                       void *stream);
+
 /* Measurement hooks (bench.py): with timing on, every GEMM / attention launch of this library is bracketed by hipEvents recorded on its launch
  * stream.  collect() waits for them and returns, per kind (0 NT GEMM, 1 TN GEMM, 2 attention forward, 3 attention backward), the summed
  * milliseconds, the summed algorithmic flops and the number of launches since the last set_timing / collect.  kinds >= 4. */

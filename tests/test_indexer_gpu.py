@@ -96,3 +96,47 @@ def test_side_stream_refresher_uses_the_snapshot_and_swaps_at_a_step_boundary():
     d2, i2 = _search(ref2)
     d3, i3 = _search(index)
     assert np.array_equal(d3, d2) and np.array_equal(i3, i2)
+
+
+def test_index_builder_against_the_oracles():
+    """a17 against independent arithmetic (not HIP vs HIP): the rows `IndexBuilder` writes into the index are the [CLS] states the fp32 oracle
+    (oracle.transformer_oracle.bert_embed, pinned on the reference's PretrainedBertModel) computes for the same weights on the evidence
+    input the reference builds for a passage -- `[CLS] title [SEP] text [SEP] pad` (data/orqa_wiki_dataset.py:68-120) -- within the bf16
+    tolerance (2e-2 of the embedding scale); and a search over the refreshed index returns exactly what the CPU MIPS oracle returns for
+    the rows actually stored (the index update path is exact)."""
+    from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex
+    from emdr2_amd.indexer_emdr2 import IndexBuilder
+    from oracle import mips_oracle as mo
+    from oracle import transformer_oracle as to
+    model, arena = _setup(n_docs=700, seed=2)
+    builder = IndexBuilder(model, arena, S_RET, CLS, SEP, PAD, batch_size=96)
+    index = DistributedBruteForceIndex(128, None)
+    ids = (np.random.default_rng(4).permutation(arena.n_docs) + 1).astype(np.int32)          # rows are not in doc-id order
+    index.add_arrays(ids, np.zeros((arena.n_docs, 128), dtype=np.float16))
+    builder.build_into_index(index)
+    stored = index.shard.rows(np.arange(arena.n_docs)).cpu().numpy()                          # fp16 rows read back out of the tiled image
+    # (1) rows vs the oracle's embeddings of the same passages
+    P = {"bert." + k: v.detach().float().cpu() for k, v in model.state_dict().items()}
+    cfg = dict(layers=2, hidden=128, heads=2, ffn=256)
+    pick = np.array([0, 1, 2, 95, 96, 300, 698, 699])
+    # the corpus arrays, read off the device and sliced on the host (independent of the assembly kernel)
+    h = {k: v.cpu().numpy() for k, v in arena.dev.items()}
+    title = lambda d: (h["title_tokens"][h["title_off"][d - 1]:h["title_off"][d]].astype(np.int64) & 0xffff).tolist()
+    passage = lambda d: (h["passage_tokens"][h["passage_off"][d - 1]:h["passage_off"][d]].astype(np.int64) & 0xffff).tolist()
+    tok = []
+    for doc in ids[pick]:
+        t = [CLS] + title(int(doc)) + [SEP] + passage(int(doc))
+        t = t[:S_RET - 1] + [SEP]
+        tok.append(t + [PAD] * (S_RET - len(t)))
+    tok = torch.tensor(tok, dtype=torch.int64)
+    types = torch.zeros_like(tok)
+    with torch.no_grad():
+        ref = to.bert_embed(P, "bert", cfg, tok, ~to.make_attention_mask_3d(tok, tok), types).numpy()
+    got = stored[pick].astype(np.float32)
+    assert np.abs(got - ref).max() <= 2e-2 * np.abs(ref).max(), np.abs(got - ref).max() / np.abs(ref).max()
+    # (2) search over the refreshed index == CPU oracle over the stored rows (scores and doc ids bit-identical)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    q = torch.randn((16, 128), generator=g, device="cuda").half()
+    d, i = index.search_mips_index(q, 10)
+    od, oi = mo.topk(stored, q.cpu().numpy(), 10, ids=ids)
+    assert np.array_equal(d.cpu().numpy().view(np.uint16), od.view(np.uint16)) and np.array_equal(i.cpu().numpy(), oi)

@@ -377,3 +377,39 @@ def test_embedding_backward_with_token_types_and_positions():
     assert rel(out, ref) < 1e-2
     assert rel(Wt.grad, Wf.grad) < 1e-2 and rel(Pt.grad, Pf.grad) < 1e-2 and rel(Tt.grad, Tf.grad) < 1e-2
     assert float(Pt.grad[s:].abs().max()) == 0.0                          # rows beyond the sequence length untouched
+
+
+@pytest.mark.parametrize("B,Kk,H,scaled", [(64, 50, 768, True), (8, 101, 768, True), (3, 7, 128, False), (5, 128, 64, True)])
+def test_retriever_prior_kernel_value_and_gradients(B, Kk, H, scaled):
+    """a9 (emdr2_model.py:134-145): log_softmax_k(<q, c_k> / sqrt(H)) and its gradients against torch fp32 autograd of the same formula."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(B * Kk + H)
+    q = torch.randn((B, H), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    c = torch.randn((B, Kk, H), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    w = torch.randn((B, Kk), generator=g, device="cuda")
+    scale = 1.0 / H ** 0.5 if scaled else 1.0
+    out = K.retriever_prior(q, c, scale)
+    (out * w).sum().backward()
+    qr, cr = q.detach().float().requires_grad_(True), c.detach().float().requires_grad_(True)
+    ref = torch.log_softmax(torch.bmm(qr[:, None, :], cr.transpose(1, 2))[:, 0] * scale, dim=1)
+    (ref * w).sum().backward()
+    assert out.dtype == torch.float32 and torch.allclose(out, ref.detach(), rtol=1e-4, atol=1e-4)
+    assert torch.allclose(q.grad.float(), qr.grad, rtol=2e-2, atol=2e-2 * float(qr.grad.abs().max()))
+    assert torch.allclose(c.grad.float(), cr.grad, rtol=2e-2, atol=2e-2 * float(cr.grad.abs().max()))
+
+
+@pytest.mark.parametrize("B,Kk,L", [(64, 50, 32), (4, 101, 32), (2, 3, 8)])
+def test_marginal_logsumexp_kernel_value_and_gradient(B, Kk, L):
+    """a14 tail (train_e2eqa.py:98-123): logsumexp_k(prior + gold) and d/d prior against torch."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(B + Kk + L)
+    prior = torch.log_softmax(torch.randn((B, Kk), generator=g, device="cuda"), dim=1).requires_grad_(True)
+    gold = -torch.rand((B, Kk, L), generator=g, device="cuda") * 12
+    w = torch.randn((B, L), generator=g, device="cuda")
+    out = K.marginal_logsumexp(prior, gold)
+    (out * w).sum().backward()
+    pr = prior.detach().clone().requires_grad_(True)
+    ref = torch.logsumexp(pr.unsqueeze(-1) + gold, dim=1)
+    (ref * w).sum().backward()
+    assert torch.allclose(out, ref.detach(), rtol=1e-5, atol=1e-5)
+    assert torch.allclose(prior.grad, pr.grad, rtol=1e-4, atol=1e-5)
