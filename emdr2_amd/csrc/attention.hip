@@ -35,11 +35,31 @@ struct AttnParams {
     uint32_t seed;
 };
 
+// exchange between lane i and lane i + 32 (the two halves of a wave hold the two key subsets of one query): v_permlane32_swap with the value
+// in both operands leaves {lower half's x, upper half's x} in every lane -- one VALU op instead of a ds_bpermute round trip through the LDS
+__device__ __forceinline__ float half_max(float x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float half_sum(float x)
+{
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 #define KB 64   // keys per block
 #define QW 32   // queries per wave
-#define QB 256  // queries per workgroup
+#define NW 4    // waves per workgroup
+#define QB (NW * QW)  // queries per workgroup
 
-__global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
+// DROP / CAUSAL are compile-time: the instances without them carry neither the hash nor the history-mask arithmetic.  The kernel is VALU-bound
+// (rocprofv3: ~35 VALU instructions per MFMA, VALU busy 4.6x the matrix pipe), so what matters is keeping the VALU issuing: two workgroups per
+// CU (4 waves per SIMD) need <= 128 VGPRs, which is why a 64-key block is consumed as two 32-key online-softmax steps (16 score registers live
+// instead of 32) and a workgroup is FOUR waves (128 queries): three workgroups per CU = 3 waves per SIMD at <= 168 VGPRs, each with its own
+// barrier, so one workgroup's softmax arithmetic runs under another's MFMAs and DMA waits.
+template <bool DROP, bool CAUSAL>
+__global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
 {
     // LDS: 2 stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h)
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
@@ -61,21 +81,24 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     for (int t = 0; t < 4; ++t) qf[t] = *(const bf16x8 *)(qrow + (16 * t + 8 * hi) * 2);
     const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
 
-    // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves piece w of each: 8 rows x 128 B,
-    // lane -> (row = 8w + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row)
+    // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves pieces w, w + NW, .. of each: 8 rows x 128 B,
+    // lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row) (tile_swz has period 8 in the row)
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
     const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
     const int nblk = (p.sk + KB - 1) / KB;
     auto issue = [&](int blk, int stage) {                                     // sk % 64 == 0 (checked on the host)
         char *sb = smem + stage * 16384;
-        const long long key = blk * KB + prow;
-        __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8 / NW; ++i) {
+            const long long key = blk * KB + prow + 8 * NW * i;
+            __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + NW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
+        }
     };
     uint32_t vtr[2][2];
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
-    for (int blk = wave; blk < nblk; blk += 8) {
+    for (int blk = wave; blk < nblk; blk += NW) {
         const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * KB + lane] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
@@ -91,8 +114,7 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
     const bool any_qpad = __builtin_amdgcn_ballot_w64(qpad) != 0ull;
     const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;      // a wave entirely inside the padding of its sequence
     float mrun = -3.0e38f, lrun = 0.f;
-    const bool drop = p.drop_p > 0.f;
-    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
     const uint32_t rh = emdr2_row_hash(p.seed, ((unsigned long long)b * p.heads + n) * p.sq + (unsigned)qc);
 
@@ -106,123 +128,110 @@ __global__ void __launch_bounds__(512) attention_fwd_kernel(AttnParams p)
         const int key0 = blk * KB;
         // A block whose keys are all masked for every query of this wave contributes exp(-10000 - m) == 0 exactly once each query has
         // seen a real key (m > -7000): skip it.  Rows that are masked everywhere (padded queries) need every block, hence any_qpad.
-        if ((kmask == 0ull || (p.causal && key0 > q0 + QW - 1)) && !any_qpad && blk > 0 &&
+        if ((kmask == 0ull || (CAUSAL && key0 > q0 + QW - 1)) && !any_qpad && blk > 0 &&
             __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
             continue;
         const char *sb = smem + stage * 16384;
+        const uint32_t av0[2] = {vtr[0][0] + (uint32_t)(stage * 16384), vtr[0][1] + (uint32_t)(stage * 16384)};
+        const uint32_t av1[2] = {vtr[1][0] + (uint32_t)(stage * 16384), vtr[1][1] + (uint32_t)(stage * 16384)};
 
-        floatx16 sacc[2];
-        if (all_qpad) {
-            // Every score of this wave is the mask value -10000: the softmax is uniform over ALL keys.  Same numbers as the general
-            // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < 2; ++j) {                                             // two 32-key online-softmax steps per staged block
+            const uint32_t km = (uint32_t)(kmask >> (32 * j));
+            const int kb0 = key0 + 32 * j;
+            if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
+                __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
+                continue;
+            floatx16 sacc;
+            if (all_qpad) {
+                // Every score of this wave is the mask value -10000: the softmax is uniform over ALL keys.  Same numbers as the general
+                // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[j][r] = 1.f;
-            mrun = MASKED2;
-            lrun += 64.f;
-        } else {
-        // ---- S^T = K Q^T : 2 key sub-blocks x 4 k-steps --------------------------------------------------------------
+                for (int r = 0; r < 16; ++r) sacc[r] = 1.f;
+                mrun = MASKED2;
+                lrun += 32.f;
+            } else {
+                // ---- S^T = K Q^T : 32 keys x 4 k-steps ---------------------------------------------------------------------------
+                const int krow = j * 32 + l31;
+                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C operand: no v_mov per register
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+                for (int t = 1; t < 4; ++t)
+                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
+                // ---- mask, online softmax (this lane: one query, 16 of the 32 keys; its half-wave partner holds the other 16) ----
+                const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0);   // wave-uniform
+                float bmax, bsum = 0.f;
+                if (!need_mask) {
+                    float mx = sacc[0];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) sacc[j][r] = 0.f;
-            const int krow = j * 32 + l31;
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+                    bmax = fmaf(mx, sc_q, c_q);                                  // sc_q >= 0: max commutes with the affine map
+                } else {
+                    bmax = -3.0e38f;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc[j], 0, 0, 0);
-            }
-        }
-        // ---- mask, online softmax (this lane: one query, 32 of the 64 keys; its half-wave partner holds the other 32) ----
-        const bool need_mask = kmask != ~0ull || (p.causal && key0 + KB - 1 > q0);   // wave-uniform
-        float bmax, bsum = 0.f;
-        if (!need_mask) {
-            float mx = sacc[0][0];
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[j][r]);
-            bmax = fmaf(mx, sc_q, c_q);                                          // sc_q >= 0: max commutes with the affine map
-        } else {
-            bmax = -3.0e38f;
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int kl = j * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;   // key inside the block
-                    const bool masked = !((kmask >> kl) & 1ull) || (p.causal && key0 + kl > qi);
-                    const float s2 = masked ? MASKED2 : fmaf(sacc[j][r], sc_q, c_q);
-                    sacc[j][r] = s2;
-                    bmax = fmaxf(bmax, s2);
+                    for (int r = 0; r < 16; ++r) {
+                        const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;          // key inside the sub-block
+                        const bool masked = !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
+                        const float s2 = masked ? MASKED2 : fmaf(sacc[r], sc_q, c_q);
+                        sacc[r] = s2;
+                        bmax = fmaxf(bmax, s2);
+                    }
                 }
-        }
-        bmax = fmaxf(bmax, __shfl_xor(bmax, 32));
-        const float mnew = fmaxf(mrun, bmax);
-        if (!need_mask) {
-            const float off = c_q - mnew;
+                bmax = half_max(bmax);
+                const float mnew = fmaxf(mrun, bmax);
+                if (!need_mask) {
+                    const float off = c_q - mnew;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc_q, off)); sacc[r] = e; bsum += e; }
+                } else {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc_q, off)); sacc[j][r] = e; bsum += e; }
-        } else {
+                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[r] - mnew); sacc[r] = e; bsum += e; }
+                }
+                bsum = half_sum(bsum);
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                lrun = lrun * alpha + bsum;
+                if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {         // the running max moved for some query of this wave
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                    for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[j][r] - mnew); sacc[j][r] = e; bsum += e; }
-        }
-        bsum += __shfl_xor(bsum, 32);
-        const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-        lrun = lrun * alpha + bsum;
-        if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {                 // the running max moved for some query of this wave
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[j][r] *= alpha;
-        }
-        mrun = mnew;
-        }
-        if (drop) {                                                               // attention dropout after the normaliser (l is un-dropped)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
+                        for (int r = 0; r < 16; ++r) oacc[jj][r] *= alpha;
+                }
+                mrun = mnew;
+            }
+            if (DROP) {                                                           // attention dropout after the normaliser (l is un-dropped)
+                const uint32_t prod0 = ((uint32_t)(kb0 + 4 * hi) >> 1) * EMDR2_PAIR_MUL;
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const uint32_t col = (uint32_t)(key0 + j * 32 + 8 * g + 4 * hi);
-                    const uint32_t b0 = emdr2_pair_bits(rh, col), b1 = emdr2_pair_bits(rh, col + 2);
-                    sacc[j][4 * g] = (b0 & 0xffffu) >= thr ? sacc[j][4 * g] * ik : 0.f;
-                    sacc[j][4 * g + 1] = (b0 >> 16) >= thr ? sacc[j][4 * g + 1] * ik : 0.f;
-                    sacc[j][4 * g + 2] = (b1 & 0xffffu) >= thr ? sacc[j][4 * g + 2] * ik : 0.f;
-                    sacc[j][4 * g + 3] = (b1 >> 16) >= thr ? sacc[j][4 * g + 3] * ik : 0.f;
+                    const uint32_t b0 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g) * EMDR2_PAIR_MUL);
+                    const uint32_t b1 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g + 1) * EMDR2_PAIR_MUL);
+                    sacc[4 * g] = (b0 & 0xffffu) >= thr ? sacc[4 * g] : 0.f;     // (the 1 / (1 - p) of the survivors is applied once, to O)
+                    sacc[4 * g + 1] = (b0 >> 16) >= thr ? sacc[4 * g + 1] : 0.f;
+                    sacc[4 * g + 2] = (b1 & 0xffffu) >= thr ? sacc[4 * g + 2] : 0.f;
+                    sacc[4 * g + 3] = (b1 >> 16) >= thr ? sacc[4 * g + 3] : 0.f;
                 }
-        }
-
-        // ---- O^T += V^T P^T : 2 d sub-blocks x 4 k-steps (16 keys each: registers 8u..8u+7 of sub-block u>>1) -------------
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            uint32_t pw[4];
-#pragma unroll
-            for (int w = 0; w < 4; ++w) {
-                const int r0 = (u & 1) * 8 + 2 * w;
-                pw[w] = pack_bf16(sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]);
             }
-            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-            // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile) by transpose reads
-            bf16x8 vt0, vt1;
-            const uint32_t av0[2] = {vtr[0][0] + (uint32_t)(stage * 16384), vtr[0][1] + (uint32_t)(stage * 16384)};
-            const uint32_t av1[2] = {vtr[1][0] + (uint32_t)(stage * 16384), vtr[1][1] + (uint32_t)(stage * 16384)};
-            switch (u) {
-            case 0: TR_FRAG2(vt0, av0, vt1, av1, 0); break;
-            case 1: TR_FRAG2(vt0, av0, vt1, av1, 1); break;
-            case 2: TR_FRAG2(vt0, av0, vt1, av1, 2); break;
-            default: TR_FRAG2(vt0, av0, vt1, av1, 3); break;
+            // ---- O^T += V^T P^T : 2 d sub-blocks x 2 k-steps (16 keys each: registers 8w..8w+7) ---------------------------------
+#pragma unroll
+            for (int w2 = 0; w2 < 2; ++w2) {
+                uint32_t pw[4];
+#pragma unroll
+                for (int w = 0; w < 4; ++w) pw[w] = pack_bf16(sacc[w2 * 8 + 2 * w], sacc[w2 * 8 + 2 * w + 1]);
+                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+                // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile, u = 2j + w2) by transpose reads
+                bf16x8 vt0, vt1;
+                if (j == 0 && w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 0);
+                else if (j == 0) TR_FRAG2(vt0, av0, vt1, av1, 1);
+                else if (w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 2);
+                else TR_FRAG2(vt0, av0, vt1, av1, 3);
+                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, pf, oacc[0], 0, 0, 0);
+                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
             }
-            oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, pf, oacc[0], 0, 0, 0);
-            oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
         }
     }
 
     // ---- normalise and store O[q, d]: lane q holds d = j*32 + (r&3) + 8(r>>2) + 4*half --------------------------------------
     if (qvalid) {
-        const float inv = 1.f / lrun;
+        const float inv = ik / lrun;                                 // survivors of the attention dropout are scaled here, once
         uint16_t *orow = (uint16_t *)p.o + (((long long)b * p.sq + qi) * p.heads + n) * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
@@ -257,6 +266,9 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.batch = batch;
     dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads));
     OpsTimer timer(OPS_ATTN_FWD, 4.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
-    hipLaunchKernelGGL(attention_fwd_kernel, grid, dim3(512), 0, (hipStream_t)stream, p);
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
