@@ -20,6 +20,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rng.h"
 
 #include "attention_common.h"
@@ -42,7 +43,14 @@ struct BwdParams {
 };
 
 // ============================================================ dq =====================================================================
-__global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
+// Like the forward (attention.hip): VALU-bound, so workgroups are FOUR waves (128 queries) at <= 168 VGPRs -- three per CU, each on its own
+// barrier -- and a staged 64-key block is consumed as two 32-key steps (one S / dP accumulator pair live); DROP / CAUSAL are compile-time.
+#define BNW 4
+#ifndef DKV_OCC
+#define DKV_OCC 2
+#endif
+template <bool DROP, bool CAUSAL>
+__global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams p)
 {
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];       // 2 stages x (K tile 8 KiB + V tile 8 KiB)
     __shared__ unsigned long long kmask_s[1024];
@@ -50,8 +58,8 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     int qblk, b, n;
-    if (!attn_decode(blockIdx.x, (p.sq + 255) / 256, p.batch * p.heads, p.heads, qblk, b, n)) return;
-    const int q0 = qblk * 256 + wave * 32;
+    if (!attn_decode(blockIdx.x, (p.sq + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const int q0 = qblk * (BNW * 32) + wave * 32;
     const int qi = q0 + l31;
     const bool qvalid = qi < p.sq;
     const int qc = qvalid ? qi : p.sq - 1;
@@ -73,7 +81,10 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
             acc += bf_lo(a.x) * bf_lo(c.x) + bf_hi(a.x) * bf_hi(c.x) + bf_lo(a.y) * bf_lo(c.y) + bf_hi(a.y) * bf_hi(c.y) +
                    bf_lo(a.z) * bf_lo(c.z) + bf_hi(a.z) * bf_hi(c.z) + bf_lo(a.w) * bf_lo(c.w) + bf_hi(a.w) * bf_hi(c.w);
         }
-        Dq = acc + __shfl_xor(acc, 32);
+        {
+            const auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
+            Dq = __uint_as_float(r_[0]) + __uint_as_float(r_[1]);
+        }
         if (qvalid && hi == 0) p.dstat[si] = Dq;
     }
     const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
@@ -87,11 +98,14 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
     const int nblk = p.sk / 64;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
-        const long long key = blk * 64 + prow;
-        __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8 / BNW; ++i) {
+            const long long key = blk * 64 + prow + 8 * BNW * i;
+            __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
+        }
     };
-    for (int blk = wave; blk < nblk; blk += 8) {
+    for (int blk = wave; blk < nblk; blk += BNW) {
         const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * 64 + lane] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
@@ -103,8 +117,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[j][r] = 0.f;
-    const bool drop = p.drop_p > 0.f;
-    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
     const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)si);
 
@@ -117,64 +130,66 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * 64;
         // every (query of this wave, key of this block) pair masked -> dS == 0: nothing to add
-        if (!wave_live || all_qpad || kmask == 0ull || (p.causal && key0 > q0 + 31)) continue;
+        if (!wave_live || all_qpad || kmask == 0ull || (CAUSAL && key0 > q0 + 31)) continue;
         const char *sb = smem + stage * 16384;
-
-        floatx16 sacc[2], pacc[2];
+        const uint32_t a0[2] = {ktr[0][0] + (uint32_t)(stage * 16384), ktr[0][1] + (uint32_t)(stage * 16384)};
+        const uint32_t a1[2] = {ktr[1][0] + (uint32_t)(stage * 16384), ktr[1][1] + (uint32_t)(stage * 16384)};
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[j][r] = 0.f; pacc[j][r] = 0.f; }
+        for (int j = 0; j < 2; ++j) {                                             // two 32-key steps per staged block
+            const uint32_t km = (uint32_t)(kmask >> (32 * j));
+            const int kb0 = key0 + 32 * j;
+            if (km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int krow = j * 32 + l31;
+            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
+            floatx16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, hi), dof[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                sacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc[j], 0, 0, 0);
-                pacc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, 2 * t + hi), dof[t], pacc[j], 0, 0, 0);
+            for (int t = 1; t < 4; ++t) {
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, 2 * t + hi), dof[t], pacc, 0, 0, 0);
             }
-        }
-        // dS^T = P^T (dP^T_eff - D); masked -> 0
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
+            // dS^T = P^T (dP^T_eff - D); masked -> 0
+            const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0) || __builtin_amdgcn_ballot_w64(qpad) != 0ull;   // wave-uniform
+            const uint32_t prod0 = DROP ? ((uint32_t)(kb0 + 4 * hi) >> 1) * EMDR2_PAIR_MUL : 0u;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint32_t b0 = 0, b1 = 0;
-                if (drop) {
-                    const uint32_t col = (uint32_t)(key0 + j * 32 + 8 * g + 4 * hi);
-                    b0 = emdr2_pair_bits(rh, col); b1 = emdr2_pair_bits(rh, col + 2);
+                if (DROP) {
+                    b0 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g) * EMDR2_PAIR_MUL);
+                    b1 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g + 1) * EMDR2_PAIR_MUL);
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const int kl = j * 32 + 8 * g + 4 * hi + e;
-                    const bool masked = qpad || !((kmask >> kl) & 1ull) || (p.causal && key0 + kl > qi);
-                    const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[j][r], sc, -pm));
-                    float gr = pacc[j][r];
-                    if (drop) {
+                    const int kl = 8 * g + 4 * hi + e;
+                    const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pm));
+                    float gr = pacc[r];
+                    if (DROP) {
                         const uint32_t bits = e < 2 ? b0 : b1;
                         gr = ((e & 1) ? (bits >> 16) : (bits & 0xffffu)) >= thr ? gr * ik : 0.f;
                     }
-                    sacc[j][r] = masked ? 0.f : pr * (gr - Dq);
+                    float ds = pr * (gr - Dq);
+                    if (need_mask) {
+                        const bool masked = qpad || !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
+                        ds = masked ? 0.f : ds;
+                    }
+                    sacc[r] = ds;
                 }
             }
-        // dQ^T += K^T dS^T
+            // dQ^T += K^T dS^T
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int r0 = (u & 1) * 8;
-            const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[u >> 1][r0], sacc[u >> 1][r0 + 1]),
-                                                                      pack_bf16(sacc[u >> 1][r0 + 2], sacc[u >> 1][r0 + 3]),
-                                                                      pack_bf16(sacc[u >> 1][r0 + 4], sacc[u >> 1][r0 + 5]),
-                                                                      pack_bf16(sacc[u >> 1][r0 + 6], sacc[u >> 1][r0 + 7])));
-            bf16x8 kt0, kt1;
-            const uint32_t a0[2] = {ktr[0][0] + (uint32_t)(stage * 16384), ktr[0][1] + (uint32_t)(stage * 16384)};
-            const uint32_t a1[2] = {ktr[1][0] + (uint32_t)(stage * 16384), ktr[1][1] + (uint32_t)(stage * 16384)};
-            switch (u) {
-            case 0: TR_FRAG2(kt0, a0, kt1, a1, 0); break;
-            case 1: TR_FRAG2(kt0, a0, kt1, a1, 1); break;
-            case 2: TR_FRAG2(kt0, a0, kt1, a1, 2); break;
-            default: TR_FRAG2(kt0, a0, kt1, a1, 3); break;
+            for (int w2 = 0; w2 < 2; ++w2) {
+                const int r0 = w2 * 8;
+                const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[r0], sacc[r0 + 1]), pack_bf16(sacc[r0 + 2], sacc[r0 + 3]),
+                                                                          pack_bf16(sacc[r0 + 4], sacc[r0 + 5]), pack_bf16(sacc[r0 + 6], sacc[r0 + 7])));
+                bf16x8 kt0, kt1;
+                if (j == 0 && w2 == 0) TR_FRAG2(kt0, a0, kt1, a1, 0);
+                else if (j == 0) TR_FRAG2(kt0, a0, kt1, a1, 1);
+                else if (w2 == 0) TR_FRAG2(kt0, a0, kt1, a1, 2);
+                else TR_FRAG2(kt0, a0, kt1, a1, 3);
+                dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dsf, dqacc[0], 0, 0, 0);
+                dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dsf, dqacc[1], 0, 0, 0);
             }
-            dqacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt0, dsf, dqacc[0], 0, 0, 0);
-            dqacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kt1, dsf, dqacc[1], 0, 0, 0);
         }
     }
     if (qvalid) {
@@ -191,7 +206,8 @@ __global__ void __launch_bounds__(512) attention_bwd_dq_kernel(BwdParams p)
 }
 
 // ========================================================== dk, dv ===================================================================
-__global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
+template <bool DROP, bool CAUSAL>
+__global__ void __launch_bounds__(BNW * 64, DKV_OCC) attention_bwd_dkv_kernel(BwdParams p)
 {
     // 2 stages x (Q tile 8 KiB + dO tile 8 KiB); per-query statistics of the block: pm, D, row hash, flags (64 each)
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
@@ -202,8 +218,8 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     int kblk, b, n;
-    if (!attn_decode(blockIdx.x, (p.sk + 255) / 256, p.batch * p.heads, p.heads, kblk, b, n)) return;
-    const int k0 = kblk * 256 + wave * 32;
+    if (!attn_decode(blockIdx.x, (p.sk + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, kblk, b, n)) return;
+    const int k0 = kblk * (BNW * 32) + wave * 32;
     const int key = k0 + l31;
     const bool wave_live = k0 < p.sk;                                   // sk % 64 == 0: a wave's 32 keys are all valid or all out of range
     const int kc = wave_live ? key : p.sk - 1;
@@ -221,9 +237,12 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
     const long long sbase = ((long long)b * p.heads + n) * p.sq;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
-        long long qr = blk * 64 + prow; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
-        __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + wave * 1024), 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8 / BNW; ++i) {
+            long long qr = blk * 64 + prow + 8 * BNW * i; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
+            __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
+        }
     };
     // per-query statistics of a block, loaded by wave 0 one block ahead into registers and written to LDS a block later, so the
     // global-load latency never sits between a barrier and the tiles' DMA
@@ -252,8 +271,7 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[j][r] = 0.f; dvacc[j][r] = 0.f; }
-    const bool drop = p.drop_p > 0.f;
-    const float ik = drop ? emdr2_keep_scale(p.drop_p) : 1.f;
+    const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
     const uint32_t colmul = ((uint32_t)kc >> 1) * 0x9e3779b1u;           // this lane's column-pair term of emdr2_pair_bits
     const bool codd = kc & 1;
@@ -271,49 +289,66 @@ __global__ void __launch_bounds__(512) attention_bwd_dkv_kernel(BwdParams p)
         }
         const int qb0 = blk * 64;
         // keys of this wave all ahead of every query of the block: P == 0 exactly and dS == 0
-        if (!wave_live || (p.causal && k0 > qb0 + 63)) continue;
+        if (!wave_live || (CAUSAL && k0 > qb0 + 63)) continue;
         const unsigned long long qreal = st_qreal[stage];
         const char *sb = smem + stage * 16384;
 
         // the block's 64 queries in two halves of 32 (keeps the live accumulators at dK, dV + one S / dP pair)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            floatx16 sacc, pacc;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) { sacc[r] = 0.f; pacc[r] = 0.f; }
+            __builtin_amdgcn_sched_barrier(0);                             // keeps the two halves' fragment reads from being hoisted together
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int qrow = j * 32 + l31;
+            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, qrow, hi), kf[0], zero, 0, 0, 0);
+            floatx16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, qrow, hi), vf[0], zero, 0, 0, 0);
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
+            for (int t = 1; t < 4; ++t) {
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, qrow, 2 * t + hi), kf[t], sacc, 0, 0, 0);
                 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, qrow, 2 * t + hi), vf[t], pacc, 0, 0, 0);
             }
-            // this lane: one key, queries ql = j*32 + 8g + 4hi + e.  sacc <- dS, pacc <- dropped P
+            // this lane: one key, queries ql = j*32 + 8g + 4hi + e.  sacc <- dS, pacc <- dropped P.  Masks are rare (padding, the causal
+            // diagonal, the last query block): a wave-uniform test picks the mask-free form of the element loop otherwise
+            const uint32_t qr32 = (uint32_t)(qreal >> (32 * j));
+            const int qh0 = qb0 + 32 * j;
+            const bool need_mask = __builtin_amdgcn_ballot_w64(kpad) != 0ull || qr32 != 0xffffffffu || (CAUSAL && k0 + 31 > qh0) || qh0 + 31 >= p.sq;
+            auto elements = [&](auto masks) {
+                constexpr bool MASKS = decltype(masks)::value;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int ql0 = j * 32 + 8 * g + 4 * hi;
-                const float4 pm4 = *(const float4 *)&st_pm[stage][ql0], d4 = *(const float4 *)&st_d[stage][ql0];
-                uint4 rh4 = make_uint4(0, 0, 0, 0);
-                if (drop) rh4 = *(const uint4 *)&st_rh[stage][ql0];
-                const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
-                const uint32_t rhv[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
+                for (int g = 0; g < 4; ++g) {
+                    const int ql0 = j * 32 + 8 * g + 4 * hi;
+                    const float4 pm4 = *(const float4 *)&st_pm[stage][ql0], d4 = *(const float4 *)&st_d[stage][ql0];
+                    uint4 rh4 = make_uint4(0, 0, 0, 0);
+                    if (DROP) rh4 = *(const uint4 *)&st_rh[stage][ql0];
+                    const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+                    const uint32_t rhv[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int r = 4 * g + e, ql = ql0 + e, qg = qb0 + ql;
-                    const bool qv = qg < p.sq;
-                    const bool masked = kpad || !((qreal >> ql) & 1ull) || (p.causal && key > qg);
-                    float pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
-                    if (!qv) pr = 0.f;                                    // rows beyond sq do not exist
-                    float gr = pacc[r], pd = pr;
-                    if (drop) {
-                        const uint32_t bits = emdr2_pair_bits_prod(rhv[e], colmul);
-                        const bool keep = (codd ? (bits >> 16) : (bits & 0xffffu)) >= thr;
-                        gr = keep ? gr * ik : 0.f;
-                        pd = keep ? pr * ik : 0.f;
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e, ql = 8 * g + 4 * hi + e, qg = qh0 + ql;
+                        bool masked = false;
+                        float pr;
+                        if (MASKS) {
+                            masked = kpad || !((qr32 >> ql) & 1u) || (CAUSAL && key > qg);
+                            pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
+                            pr = qg < p.sq ? pr : 0.f;                        // rows beyond sq do not exist
+                        } else {
+                            pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pmv[e]));
+                        }
+                        float gr = pacc[r], pd = pr;
+                        if (DROP) {
+                            const uint32_t bits = emdr2_pair_bits_prod(rhv[e], colmul);
+                            const float km_ = (codd ? (bits >> 16) : (bits & 0xffffu)) >= thr ? ik : 0.f;
+                            gr *= km_;
+                            pd *= km_;
+                        }
+                        const float ds = pr * (gr - dv_[e]);
+                        sacc[r] = MASKS ? (masked ? 0.f : ds) : ds;
+                        pacc[r] = pd;
                     }
-                    sacc[r] = masked ? 0.f : pr * (gr - dv_[e]);
-                    pacc[r] = pd;
                 }
-            }
+            };
+            if (need_mask) elements(std::true_type{});
+            else elements(std::false_type{});
+            __builtin_amdgcn_sched_barrier(0);
             // dV^T += dO^T P_d ; dK^T += Q^T dS  (k index = the 16 queries of k-step u = 2j, 2j+1)
 #pragma unroll
             for (int uu = 0; uu < 2; ++uu) {
@@ -384,7 +419,15 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch;
     OpsTimer timer(OPS_ATTN_BWD, 10.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
-    hipLaunchKernelGGL(attention_bwd_dq_kernel, dim3(attn_grid((sq + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
-    hipLaunchKernelGGL(attention_bwd_dkv_kernel, dim3(attn_grid((sk + 255) / 256, batch * heads)), dim3(512), 0, (hipStream_t)stream, p);
+    const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads));
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_bwd_dq_kernel<false, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    const dim3 kv_grid(attn_grid((sk + BNW * 32 - 1) / (BNW * 32), batch * heads));
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, true>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, false>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, false>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
