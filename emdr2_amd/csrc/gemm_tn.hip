@@ -15,12 +15,16 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "ops_timing.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __attribute__((address_space(1))) const void gptr_t;
 typedef __attribute__((address_space(3))) void lptr_t;
+
+int emdr2_gemm8t_try(const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, int I, int J, int R, int split_k,
+                     float *colsum_a, hipStream_t stream);       // gemm8t.hip
 
 namespace {
 
@@ -201,6 +205,16 @@ extern "C" int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int
 {
     if (!A || !B || !C || I < 8 || J < 8 || R < 32 || (R & 31) || split_k < 1) return -1;
     if ((I & 7) || (J & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return -1;
+    OpsTimer timer(OPS_GEMM_TN, 2.0 * I * (double)J * R, (hipStream_t)stream);
+    bool general_only = false;
+#ifdef EMDR2_EXPERIMENTS
+    static const bool tn_old = getenv("EMDR2_TN_OLD") && atoi(getenv("EMDR2_TN_OLD"));
+    general_only = tn_old;
+#endif
+    if (!general_only) {
+        const int rc = emdr2_gemm8t_try(A, lda, B, ldb, C, ldc, I, J, R, split_k, colsum_a, (hipStream_t)stream);
+        if (rc != -4) return rc;
+    }
     TnParams p;
     p.A = (const char *)A; p.B = (const char *)B; p.C = C; p.colsum = colsum_a;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.I = I; p.J = J; p.R = R; p.splitk = split_k;
@@ -212,7 +226,6 @@ extern "C" int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int
     }
     p.tiles_i = (I + 255) / 256; p.tiles_j = (J + 255) / 256;
     dim3 grid((unsigned)(((p.tiles_i * p.tiles_j * split_k + 7) / 8) * 8));
-    OpsTimer timer(OPS_GEMM_TN, 2.0 * I * (double)J * R, (hipStream_t)stream);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(512), LDS, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

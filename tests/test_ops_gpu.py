@@ -238,7 +238,8 @@ def test_embedding_dropout_forward_and_backward():
     assert rel(Wt.grad, Wf.grad) < 2e-2 and rel(Pt.grad, Pf.grad) < 2e-2
 
 
-@pytest.mark.parametrize("M,N,Kd", [(64, 256, 256), (4096, 768, 768), (65536, 768, 512), (2048, 2304, 768), (1024, 40, 72), (8192, 3072, 768)])
+@pytest.mark.parametrize("M,N,Kd", [(64, 256, 256), (128, 512, 264), (384, 768, 768), (4096, 768, 768), (65536, 768, 512), (2048, 2304, 768), (1024, 40, 72), (8192, 3072, 768),
+                                    (36864, 520, 1032)])
 def test_weight_gradient_gemm_tn_with_bias_gradient(M, N, Kd):
     """dW = dy^T x through the LDS transpose reads (no HBM transposes), asymmetric random operands (a transposed or permuted fragment
     cannot pass), plus the fused column sums of dy."""
