@@ -1,0 +1,130 @@
+"""PMC evidence for the reader GEMMs (GPU).  Two modes:
+
+  python tools/gemm_pmc.py run
+      the workload rocprofv3 wraps: for every configuration of CONFIGS, LAUNCHES launches of the persistent NT GEMM (csrc/gemm8.hip) or of the
+      weight-gradient GEMM (csrc/gemm8t.hip), in a fixed order, nothing else on the device in between
+  python tools/gemm_pmc.py summarize <rocprof dir> [<rocprof dir> ...] [--shapes <gemm_shapes.json>] --out profiles/r02_gemm_summary.json
+      maps the kernel dispatches of each pass (in order) back to CONFIGS and writes, per configuration: mean duration, TFLOP/s, and every
+      counter collected (FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for 16-byte streaming reads on gfx950)
+
+Collect with one pass per counter group (never together with the hip/hsa trace domains), e.g.
+  tools/pmc_pass.sh gemm "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES" "TCC_HIT_sum TCC_MISS_sum" \
+      -- python $PWD/tools/gemm_pmc.py run"""
+import collections
+import csv
+import glob
+import json
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+M_FULL = 3200 * 512
+LAUNCHES = 3
+# (kind, M, N, K, epilogue)
+CONFIGS = [("nt", M_FULL, N, K, e) for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))
+           for e in ("plain", "bias", "bias+gelu", "bias+res", "bias+drop+res", "gelu'")] + \
+          [("tn", M_FULL, N, K, "colsum") for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))]
+
+
+def run():
+    import torch
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def rnd(*s):
+        return (torch.randn(s, generator=g, device="cuda") * 0.5).bfloat16()
+    last = None
+    for kind, M, N, Kd, epi in CONFIGS:
+        if (kind, N, Kd) != last:
+            a = rnd(M, Kd)
+            b = rnd(N, Kd) if kind == "nt" else rnd(M, N)
+            c = torch.empty((M, N), dtype=torch.bfloat16, device="cuda") if kind == "nt" else None
+            bias, r = torch.zeros(N, device="cuda"), (rnd(M, N) if kind == "nt" else None)
+            last = (kind, N, Kd)
+        for _ in range(LAUNCHES):
+            if kind == "tn":
+                K.weight_grad_tn(b, a, colsum=bias)          # dW [N, K] = dy [M, N]^T x [M, K]
+            else:
+                kw = {}
+                if "bias" in epi: kw["bias"] = bias
+                if "gelu" in epi.split("+"): kw["gelu"] = True
+                if "res" in epi.split("+"): kw["residual"] = r
+                if "drop" in epi: kw.update(drop_p=0.1, seed=7)
+                if epi == "gelu'": kw.update(residual=r, residual_mode=1)
+                K.gemm_nt(a, Kd, b, Kd, c, N, M, N, Kd, **kw)
+        torch.cuda.synchronize()
+
+
+def summarize(dirs, shapes_json, out):
+    per = [dict(kind=k, M=M, N=N, K=Kd, epilogue=e, counters={}) for k, M, N, Kd, e in CONFIGS]
+    for d in dirs:
+        kt = glob.glob(os.path.join(d, "*", "*kernel_trace.csv"))
+        cc = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
+        if not kt or not cc:
+            continue
+        disp = [r for r in csv.DictReader(open(kt[0])) if "gemm8" in r["Kernel_Name"]]
+        disp.sort(key=lambda r: int(r["Start_Timestamp"]))
+        assert len(disp) == len(CONFIGS) * LAUNCHES, (d, len(disp))
+        ctr = collections.defaultdict(dict)
+        for r in csv.DictReader(open(cc[0])):
+            ctr[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        for i, cfg in enumerate(per):
+            mine = disp[i * LAUNCHES:(i + 1) * LAUNCHES]
+            cfg.setdefault("_dur", []).extend((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in mine)
+            names = set().union(*(ctr[r["Dispatch_Id"]].keys() for r in mine))
+            for n in names:
+                v = [ctr[r["Dispatch_Id"]][n] for r in mine if n in ctr[r["Dispatch_Id"]]]
+                cfg["counters"][n] = sum(v) / len(v)
+    for cfg in per:
+        dur = cfg.pop("_dur", [])
+        if not dur:
+            continue
+        ms = sum(dur) / len(dur)
+        fl = 2.0 * cfg["M"] * cfg["N"] * cfg["K"]
+        cfg["ms_per_launch_under_pmc"] = round(ms, 3)
+        cfg["tflops_under_pmc"] = round(fl / (ms * 1e-3) / 1e12, 1)
+        c = cfg["counters"]
+        algo = 2.0 * (cfg["M"] * cfg["K"] + cfg["N"] * cfg["K"] + cfg["M"] * cfg["N"]) if cfg["kind"] == "nt" else 2.0 * cfg["M"] * (cfg["N"] + cfg["K"])
+        if "res" in cfg["epilogue"] or cfg["epilogue"] == "gelu'":
+            algo += 2.0 * cfg["M"] * cfg["N"]
+        cfg["algorithmic_hbm_gb"] = round(algo / 1e9, 3)
+        if "FETCH_SIZE" in c:
+            cfg["hbm_read_gb"] = round(2.0 * c["FETCH_SIZE"] * 1024 / 1e9, 3)          # KB, x2: gfx950 tallies 128-B read requests at 64 B
+        if "WRITE_SIZE" in c:
+            cfg["hbm_write_gb_uncalibrated"] = round(c["WRITE_SIZE"] * 1024 / 1e9, 3)
+        if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
+            # MFMA-busy cycles are summed over the 1,024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
+            cfg["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
+            cfg["shader_clock_ghz"] = round(c["GRBM_GUI_ACTIVE"] / 8.0 / (ms * 1e6), 3)
+        if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+            cfg["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
+        cfg["counters"] = {k: round(v, 1) for k, v in sorted(c.items())}
+    res = {"what": "reader GEMM kernels one by one at the end-to-end step's shapes (M = 3200 x 512 token rows): %d launches per configuration, mean per launch; "
+                   "counters from separate rocprofv3 --pmc passes (kernel-trace only)" % LAUNCHES,
+           "notes": ["tflops_under_pmc is measured while counters are being collected (a few % slower than free-running)",
+                     "hbm_read_gb = 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section); WRITE_SIZE is reported as is",
+                     "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): the fraction of cycles the matrix pipe works, at the "
+                     "clock the launch actually ran at (shader_clock_ghz; the 2.5 PFLOP/s peak assumes 2.4 GHz)"],
+           "per_kernel": per}
+    if shapes_json and os.path.exists(shapes_json):
+        res["end_to_end_step"] = json.load(open(shapes_json))
+    with open(out, "w") as f:
+        json.dump(res, f, indent=1)
+    for cfg in per:
+        print("%-2s N=%-5d K=%-5d %-14s %8s ms %7s TF  mfma busy %-6s clock %-6s read %-7s GB (algorithmic total %-7s GB)  L2 hit %s" % (
+            cfg["kind"], cfg["N"], cfg["K"], cfg["epilogue"], cfg.get("ms_per_launch_under_pmc"), cfg.get("tflops_under_pmc"), cfg.get("mfma_busy_frac"),
+            cfg.get("shader_clock_ghz"), cfg.get("hbm_read_gb"), cfg.get("algorithmic_hbm_gb"), cfg.get("l2_hit_rate")))
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "run":
+        run()
+    elif len(sys.argv) > 1 and sys.argv[1] == "summarize":
+        args = sys.argv[2:]
+        shapes = args[args.index("--shapes") + 1] if "--shapes" in args else ""
+        out = args[args.index("--out") + 1]
+        dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] not in ("--shapes", "--out"))]
+        summarize(dirs, shapes, out)
+    else:
+        print(__doc__)

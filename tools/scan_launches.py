@@ -4,6 +4,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from emdr2_amd import _native
+if "--exp" in sys.argv:                                     # experiments build: EMDR2_MIPS_ABLATE / _KERNEL / _VARIANT switches are live
+    _native.LIB_PATH = _native.LIB_PATH.replace("libemdr2_hip.so", "libemdr2_hip_exp.so")
+    sys.argv.remove("--exp")
 from emdr2_amd.data.emdr2_index import HipIndexShard
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else bench.N_ROWS_FULL
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 512
