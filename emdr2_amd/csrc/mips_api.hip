@@ -206,7 +206,11 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
             else if (mode == 0 && scan_kernel == 4) rc = mips_launch_scan_pp(variant, seg_end == n_rows && done >= n_rows / 16 ? 4 : 3, sp, grid, stream);
             else
 #endif
-            rc = mips_launch_scan(variant, mode, sp, grid, stream);
+            {
+                rc = -4;
+                if (mode == 0 && variant <= 1 && scan_kernel == 1) rc = mips_launch_scan8(sp, BN, done, seg_end, cus, stream);
+                if (rc == -4) rc = mips_launch_scan(variant, mode, sp, grid, stream);
+            }
             if (rc) return rc;
             if (timed) {
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n + 1], stream) != hipSuccess) return EMDR2_E_LAUNCH;

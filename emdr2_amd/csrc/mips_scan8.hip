@@ -1,0 +1,319 @@
+// emdr2_amd/csrc/mips_scan8.hip -- the index scan for 129..512 queries per pass in the pipeline of the persistent GEMM (gemm8.hip): fused fp16 MFMA
+// GEMM  S = E Q^T  + threshold filter, S never materialised.
+//
+// Replaces, like mips_scan.hip, the reference's dense  C = Q * E^T  + torch.topk (megatron/data/emdr2_index.py:281-295) for the filter
+// segments (mode 0) of a search; same inputs (stripe-tiled index image, chunk-tiled query image, per-query thresholds) and the same
+// survivor protocol (LDS queue -> per-query candidate buffers), so the select / finalize kernels downstream are unchanged and the results are
+// bit-identical by construction (every (row, query) score is the same fp32 MFMA sum over k in the same order: chunks ascending, the four
+// 16-wide k-steps of a K-tile ascending).
+//
+// What changes against mips_scan.hip (128 rows x 512 queries per workgroup, 32-wide chunks, 3-stage lockstep ring: 915 TFLOP/s, the LDS-DMA
+// fill and the MFMA phase nearly additive):
+//  * work item = 256 index rows x 256 queries (one half of the 512-query image): 64 KiB of L2->LDS fill per 8.4 MFLOP instead of 40 KiB per
+//    4.2 MFLOP.  The two halves of a row tile are adjacent items, taken by two CUs of the same XCD in the same round: the index rows leave
+//    HBM once, the partner reads them from L2.
+//  * K-tile = 64 (two 8 KiB chunk images per stripe), 2 x 4 half-tile slots, four phases per K-tile with 8 MFMAs behind 12 / 4 / 8 / 0 fragment
+//    reads and one half-tile of LDS-DMA six half-tiles ahead (vmcnt(8)), the two wave halves one barrier apart, persistent DMA stream across
+//    items: the schedule of gemm8.hip, which the same measurements put at 1,300 TFLOP/s without an output epilogue.
+//  * the epilogue is the filter: per accumulator block a max + one ballot in the common case (no survivor).
+// LDS: 128 KiB operand ring + 32 KiB survivor queue.
+#include "mips_device.h"
+#include "mips_kernels.h"
+
+namespace {
+
+#define S8_BUF 65536
+#define S8_SLOT 16384
+#define S8_QCAP 2040              // survivor queue entries (16 B each); the counter sits behind them
+#define S8_FLUSH_AT 1024
+
+struct Scan8Params {
+    ScanParams s;
+    int t_begin, t_end;           // 256-row tiles
+    int halves;                   // 256-query halves of the query image (1 or 2)
+    int bn;                       // rows of the query image (256 or 512)
+    int last_stripe;              // highest 128-row stripe that exists
+    int total, per;               // items, items per XCD
+};
+
+__device__ __forceinline__ void s8_flush(const ScanParams &p, const char *qbuf, unsigned n, int tid)
+{
+    const unsigned m = n < S8_QCAP ? n : S8_QCAP;
+    for (unsigned i = tid; i < m; i += 512) {
+        const uint4 e = ((const uint4 *)qbuf)[i];
+        const unsigned slot = atomicAdd(&p.count[e.z], 1u);
+        if (slot < p.capq) p.cand[(size_t)e.z * p.capq + slot] = make_uint2(e.x, e.y);
+        else atomicOr(&p.flags[e.z], 2u);
+    }
+}
+
+__global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const ScanParams &p = P.s;
+    char *const qbuf = smem + 2 * S8_BUF;
+    unsigned *const qcnt = (unsigned *)(qbuf + S8_QCAP * 16);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;                 // wave grid 2 (rows) x 4 (queries); wr is also the half that runs one barrier behind
+    const int l31 = lane & 31, hi = lane >> 5;
+
+    // ---- this workgroup's items: XCD x = id & 7 owns sequence positions [x * per, (x + 1) * per), its workgroups take them round-robin; an item
+    // is (row tile, query half) with the half fastest, so both halves of a tile run at the same time on one L2
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, wg_per_xcd = gridDim.x >> 3;
+    const int seq_lo = xcd * P.per;
+    int seq_hi = seq_lo + P.per; if (seq_hi > P.total) seq_hi = P.total;
+    const int first = seq_lo + slot;
+    if (first >= seq_hi) return;
+    const int my_count = (seq_hi - first + wg_per_xcd - 1) / wg_per_xcd;
+    const int KT = p.nch >> 1;                                // K-tiles of 64 = pairs of 32-wide chunks; even (host)
+    if (tid == 0) *qcnt = 0;
+    // the workgroups of an XCD stride the sequence by an even count (host) and `per` is even: a workgroup keeps ONE query half for all its items,
+    // so its thresholds are loaded once (a load in the filter would wait out the whole DMA queue: vmcnt is in order)
+    const int hq = P.halves == 2 ? first & 1 : 0;
+    float tauv[2];
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int q = hq * 256 + wc * 64 + ni * 32 + l31;
+        tauv[ni] = q < p.n_q ? p.tau[q] : __builtin_inff();
+    }
+
+    // ---- LDS-DMA addressing.  The operand images in HBM are LDS images already (mips_device.h: 64-byte rows, 16-byte groups XOR-swizzled with
+    // (row >> 2) & 3), so every piece is a linear 1 KiB copy.  Half-tile slots:
+    //   A_h (rows [64 h, 64 h + 64) of both stripes):  [stripe 2][chunk 2][64 rows x 64 B]     piece pa = stripe * 8 + chunk * 4 + quarter
+    //   B_h (queries [32 h, 32 h + 32) of every wave):  [wave column 4][chunk 2][32 rows x 64 B] piece pb = wc * 4 + chunk * 2 + half
+    // wave w moves pieces w and w + 8 of every half-tile.
+    const int ja = (wave >> 2) & 1, qa = wave & 3;            // A pieces w, w + 8: stripes 0 / 1, chunk ja, quarter qa
+    const int jb = (wave >> 1) & 1, qb = wave & 1;            // B pieces w, w + 8: wave columns w >> 2 and 2 + (w >> 2), chunk jb, half qb
+    const uint32_t offA = (uint32_t)(ja * STRIPE_CHUNK_BYTES + qa * 1024 + lane * 16);
+    const uint32_t q_stage = (uint32_t)P.bn * 64;             // bytes of one 32-wide chunk of the query image
+    const uint32_t offB = (uint32_t)(jb * q_stage + ((wave >> 2) * 64) * 64 + qb * 1024 + lane * 16);
+    // stage cursor (wave-uniform): item `s_i` of this workgroup's list, K-tile `s_kt`
+    int s_i = 0, s_kt = 0;
+    const char *sA0, *sA1, *sB;
+    auto cursor_item = [&](int i) {
+        if (i >= my_count) i = my_count - 1;                  // past the end: harmless re-reads keep the vmcnt arithmetic fixed
+        const int pos = first + i * wg_per_xcd;
+        const int tile = P.t_begin + (P.halves == 2 ? pos >> 1 : pos);
+        int st0 = tile * 2, st1 = tile * 2 + 1;
+        if (st0 > P.last_stripe) st0 = P.last_stripe;         // rows past the end of the shard: re-read the last stripe (masked by row < n_rows)
+        if (st1 > P.last_stripe) st1 = P.last_stripe;
+        sA0 = p.e_tiled + (size_t)st0 * p.nch * STRIPE_CHUNK_BYTES;
+        sA1 = p.e_tiled + (size_t)st1 * p.nch * STRIPE_CHUNK_BYTES;
+        sB = p.q_tiled + (size_t)hq * 256 * 64;
+    };
+    cursor_item(0);
+#define S8_STAGE(T, SB)                                                                                                                   \
+    do {                                                                                                                                  \
+        char *dst_ = smem + (SB) * S8_BUF + (T) * S8_SLOT + wave * 1024;                                                                   \
+        if ((T) == 0 || (T) == 3) {                                                                                                       \
+            const uint32_t o_ = offA + ((T) == 3 ? 4096 : 0);                                                                             \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(sA0 + o_), (lptr_t *)dst_, 16, 0, 0);                                             \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(sA1 + o_), (lptr_t *)(dst_ + 8192), 16, 0, 0);                                    \
+        } else {                                                                                                                          \
+            const uint32_t o_ = offB + ((T) == 2 ? 32 * 64 : 0);                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(sB + o_), (lptr_t *)dst_, 16, 0, 0);                                              \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(sB + o_ + 128 * 64), (lptr_t *)(dst_ + 8192), 16, 0, 0);                          \
+        }                                                                                                                                 \
+        if ((T) == 3) {                                                                                                                   \
+            sA0 += 2 * STRIPE_CHUNK_BYTES; sA1 += 2 * STRIPE_CHUNK_BYTES; sB += 2 * q_stage;                                              \
+            if (++s_kt == KT) { s_kt = 0; cursor_item(++s_i); }                                                                           \
+        }                                                                                                                                 \
+    } while (0)
+
+    // ---- fragment reads: lane reads row l31 of a 32-row block, 16-byte group ((ks & 1) * 2 + hi) ^ ((row >> 2) & 3) of chunk ks >> 1
+    const int swz = (l31 >> 2) & 3;
+    int a_rd[4], b_rd[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int g = ((((ks & 1) * 2 + hi) ^ swz) << 4);
+        a_rd[ks] = wr * 8192 + (ks >> 1) * 4096 + l31 * 64 + g;
+        b_rd[ks] = wc * 4096 + (ks >> 1) * 2048 + l31 * 64 + g;
+    }
+    half8 av[2][4], b0v[4], b1v[4];
+#define S8_READ_A(BUF, MH)                                                                                                                \
+    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                         \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
+            av[f][ks] = *(const half8 *)(smem + (BUF) * S8_BUF + ((MH) ? 3 * S8_SLOT : 0) + f * 2048 + a_rd[ks])
+#define S8_READ_B(BUF, NH, DST)                                                                                                           \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
+        DST[ks] = *(const half8 *)(smem + (BUF) * S8_BUF + ((NH) ? 2 * S8_SLOT : S8_SLOT) + b_rd[ks])
+    // rows of the MFMA result = index rows (A fragment first), columns = queries: a lane holds ONE query and 16 rows per accumulator block
+#define S8_MFMA(MH, NH, BV)                                                                                                               \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
+            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[f][ks], BV[ks], acc[2 * (MH) + f][NH], 0, 0, 0)
+#define S8_SYNC_COMPUTE(BETWEEN, MFMAS)                                                                                                   \
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+    __builtin_amdgcn_s_barrier();                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+    BETWEEN;                                                                                                                              \
+    __builtin_amdgcn_s_setprio(1);                                                                                                        \
+    MFMAS;                                                                                                                                \
+    __builtin_amdgcn_s_setprio(0);                                                                                                        \
+    __builtin_amdgcn_sched_barrier(0)
+#define S8_BARRIER()                                                                                                                      \
+    __builtin_amdgcn_s_barrier();                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0)
+    // Queue high-water check.  Both wave halves run it in the SAME barrier interval -- the first one after all pushes of the finished item
+    // (leading half: right behind the first barrier of the next item; trailing half: right behind its seam barrier) -- so the decision is
+    // uniform, and the two barriers inside pair up half against half.
+#define S8_MAYBE_FLUSH()                                                                                                                  \
+    do {                                                                                                                                  \
+        const unsigned n_ = *(volatile __attribute__((address_space(3))) unsigned *)qcnt;                                                  \
+        if (n_ >= S8_FLUSH_AT) {                                                                                                          \
+            s8_flush(p, qbuf, n_, tid);                                                                                                   \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                              \
+            S8_BARRIER();                                                                                                                 \
+            if (tid == 0) *qcnt = 0;                                                                                                      \
+            S8_BARRIER();                                                                                                                 \
+        }                                                                                                                                 \
+    } while (0)
+
+    floatx16 acc[4][2];
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // ---- prologue: the first six half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
+    S8_STAGE(0, 0); S8_STAGE(1, 0); S8_STAGE(2, 0); S8_STAGE(3, 0); S8_STAGE(0, 1); S8_STAGE(1, 1);
+    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0 of K-tile 0 have landed (this wave's pieces)
+    S8_BARRIER();                                             // (also publishes the queue counter reset)
+    if (wr == 1) { S8_BARRIER(); }
+
+    for (int ti = 0; ti < my_count; ++ti) {
+        for (int kt2 = 0; kt2 < KT; kt2 += 2) {
+            // ---- K-tile in buffer 0
+            S8_READ_B(0, 0, b0v); S8_READ_A(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(2, 1);
+            S8_SYNC_COMPUTE(if (wr == 0 && kt2 == 0 && ti > 0) S8_MAYBE_FLUSH(), S8_MFMA(0, 0, b0v));
+            S8_BARRIER();
+            S8_READ_B(0, 1, b1v);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(3, 1);
+            S8_SYNC_COMPUTE(, S8_MFMA(0, 1, b1v));
+            S8_BARRIER();
+            S8_READ_A(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(0, 0);
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 1, b1v));
+            S8_BARRIER();
+            S8_STAGE(1, 0);
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));
+            S8_BARRIER();
+            // ---- K-tile in buffer 1
+            S8_READ_B(1, 0, b0v); S8_READ_A(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(2, 0);
+            S8_SYNC_COMPUTE(, S8_MFMA(0, 0, b0v));
+            S8_BARRIER();
+            S8_READ_B(1, 1, b1v);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(3, 0);
+            S8_SYNC_COMPUTE(, S8_MFMA(0, 1, b1v));
+            S8_BARRIER();
+            S8_READ_A(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            S8_STAGE(0, 1);
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 1, b1v));
+            S8_BARRIER();
+            S8_STAGE(1, 1);
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));
+            if (kt2 + 2 < KT) { S8_BARRIER(); }
+        }
+        // ---- item seam.  The leading half is past its last MFMAs one barrier interval before the trailing half: it takes the closing barrier of
+        // the last phase first, the trailing half after its filter, so both filters run in the same interval.
+        if (wr == 0) { S8_BARRIER(); }
+
+        const int pos = first + ti * wg_per_xcd;
+        const int tile = P.t_begin + (P.halves == 2 ? pos >> 1 : pos);
+        // lane ids rebuilt per item (v_mbcnt): hoisted to kernel entry they would be live across the whole main loop
+        const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+        const int e31 = elane & 31, ehi = elane >> 5;
+        const int row_w = tile * 256 + wr * 128 + 4 * ehi;    // + 64 mh + 32 f + (r & 3) + 8 (r >> 2)
+        bool stored = false;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const unsigned q = (unsigned)(hq * 256 + wc * 64 + ni * 32 + e31);
+            const float tau = tauv[ni];
+            float m = acc[0][ni][0];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+            if (__builtin_amdgcn_ballot_w64(m >= tau) != 0) {                      // rare: some (row, query) of this block passes
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const float v = acc[mi][ni][r];
+                        const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        const bool pass = (v >= tau) && (row < p.n_rows);
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                        if (mask == 0) continue;
+                        unsigned base = 0;
+                        if (elane == 0) base = atomicAdd(qcnt, (unsigned)__popcll(mask));
+                        base = __builtin_amdgcn_readfirstlane(base);
+                        if (pass) {
+                            const unsigned slot_ = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            if (slot_ < S8_QCAP) {
+                                ((uint4 *)qbuf)[slot_] = make_uint4(__float_as_uint(v), (unsigned)row, q, 0u);
+                            } else {                                               // queue full: straight to the candidate buffer
+                                const unsigned g = atomicAdd(&p.count[q], 1u);
+                                if (g < p.capq) p.cand[(size_t)q * p.capq + g] = make_uint2(__float_as_uint(v), (unsigned)row);
+                                else atomicOr(&p.flags[q], 2u);
+                                stored = true;
+                            }
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+        }
+        if (__builtin_amdgcn_ballot_w64(stored)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wr == 1) {
+            S8_BARRIER();
+            if (ti + 1 < my_count) S8_MAYBE_FLUSH();
+        }
+    }
+    if (wr == 0) { S8_BARRIER(); }                            // the leading half pays back the barrier the trailing half took at the start
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // speculative half-tiles past the end of the stream
+    S8_BARRIER();
+    s8_flush(p, qbuf, *(volatile __attribute__((address_space(3))) unsigned *)qcnt, tid);
+}
+
+} // namespace
+
+// Filter scan (mode 0) of rows [row_begin, row_end) for a query image of `bn` = 256 or 512 rows; -4 = not covered (the caller uses mips_scan.hip)
+int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, hipStream_t stream)
+{
+    if ((bn != 256 && bn != 512) || (p.nch & 3) || p.nch < 4 || (row_begin & 255) || row_end <= row_begin) return -4;
+    Scan8Params P;
+    P.s = p;
+    P.bn = bn; P.halves = bn / 256;
+    P.t_begin = (int)(row_begin >> 8);
+    P.t_end = (int)((row_end + 255) >> 8);
+    P.last_stripe = (int)((p.n_rows + STRIPE_ROWS - 1) / STRIPE_ROWS) - 1;
+    P.total = (P.t_end - P.t_begin) * P.halves;
+    int grid = cus & ~15;                                     // a multiple of 8 XCDs x an even number of workgroups each
+    if (grid < 16) grid = 16;
+    if (P.total < grid) return -4;                            // short segments stay on the non-persistent kernel
+    P.per = ((P.total + 7) >> 3);
+    P.per = (P.per + 1) & ~1;                                 // both halves of a tile on the same XCD
+    constexpr int LDS = 2 * S8_BUF + S8_QCAP * 16 + 128;
+    static bool attr_done = false;
+    if (!attr_done) {
+        if (hipFuncSetAttribute((const void *)mips_scan8_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL(mips_scan8_kernel, dim3(grid), dim3(512), LDS, stream, P);
+    return hipGetLastError() == hipSuccess ? 0 : -3;
+}

@@ -119,6 +119,30 @@ def test_adversarial_row_order_overflows_and_falls_back():
     assert_bit_identical(d, i, od, oi)
 
 
+@pytest.mark.parametrize("hot_frac,nq", [(0.01, 300), (0.2, 300), (0.01, 200)])
+def test_persistent_filter_scan_queue_flush_and_overflow(hot_frac, nq):
+    """The 256 x 256 persistent scan (csrc/mips_scan8.hip: 129..512 queries, filter segments of >= 256 items): late rows that beat the running
+    thresholds of EVERY query make each work item push hundreds (1 %: mid-kernel queue flushes) or thousands (20 %: queue overflow straight
+    to the candidate buffers, candidate buffers overflow, exact fallback) of survivors.  Results stay bit-identical to the oracle."""
+    rng = np.random.default_rng(int(hot_frac * 1000) + nq)
+    n, dim, k = 300_000, 128, 50
+    u = rng.standard_normal(dim); u /= np.linalg.norm(u)
+    q = (u[None, :] + 0.05 * rng.standard_normal((nq, dim))).astype(np.float16)
+    rows = (0.05 * rng.standard_normal((n, dim))).astype(np.float16)
+    hot = np.nonzero(rng.random(n) < hot_frac)[0]
+    hot = hot[hot >= 140_000]
+    rows[hot] = (u[None, :] * (1.0 + rng.random((hot.size, 1))) + 0.05 * rng.standard_normal((hot.size, dim))).astype(np.float16)
+    sh = _shard(rows)
+    d, i, r, f = _search(sh, q, k)
+    od, oi, orow = mo.topk(rows, q, k, return_rows=True)
+    assert (f == 0).all()
+    assert_bit_identical(d, i, od, oi)
+    assert np.array_equal(r, orow)
+    if hot_frac < 0.1:                                        # survivors fit the candidate buffers: the fast path proves itself
+        _, _, _, f0 = _search(sh, q, k, exact_fallback=False)
+        assert (f0 == 0).all()
+
+
 def test_shard_count_invariance_with_hip_merge():
     from emdr2_amd.data.emdr2_index import merge_shard_results, shard_bounds
     case = mips_cases.case_realistic()
