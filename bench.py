@@ -221,18 +221,18 @@ def main():
                     "unit": "TFLOP/s" if bound == "mfma" else "GB/s",
                     "frac": (tflops / MFMA_PEAK_TFLOPS) if bound == "mfma" else (gbps / HBM_PEAK_GBPS),
                     "traffic": None,
-                    "kernel": "mips_scan_kernel (last row segment: %d rows/launch)" % big,
+                    "kernel": "mips_scan8_kernel (last row segment: %d rows/launch)" % big,
                     "kernel_ms": dom_ms, "scan_ms_per_step": scan_ms_per_step,
                     "hbm_gbps": gbps, "hbm_frac": gbps / HBM_PEAK_GBPS,
                     "mfma_tflops": tflops, "mfma_frac": tflops / MFMA_PEAK_TFLOPS}
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE); only quoted when the profile was taken on this exact launch shape.
-        prof = os.path.join(ROOT, "profiles", "r01_final_summary.json")
+        prof = os.path.join(ROOT, "profiles", "r02_mips_summary.json")
         if os.path.exists(prof):
             pj = json.load(open(prof))
             if pj.get("algorithmic_bytes_last_segment") == int(bytes_alg) and nq == 512:
                 roofline["traffic"] = pj["traffic_bytes"]
-                roofline["traffic_source"] = "profiles/r01_final_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
+                roofline["traffic_source"] = "profiles/r02_mips_summary.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; L2->fabric requests, Infinity-Cache hits included)"
         result = {
             "metric": "mips_queries_per_sec", "value": nq * args.steps / elapsed, "unit": "queries/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,

@@ -179,6 +179,9 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
+#ifdef EMDR2_EXPERIMENTS
+    if (hq == 1) for (int i = 0; i < P.s.tune >> 8; ++i) __builtin_amdgcn_s_sleep(32);      // EMDR2_MIPS_TUNE bits 8..: late start of the second half, 2,048 cycles each
+#endif
     // ---- prologue: the first six half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
     S8_STAGE(0, 0); S8_STAGE(1, 0); S8_STAGE(2, 0); S8_STAGE(3, 0); S8_STAGE(0, 1); S8_STAGE(1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0 of K-tile 0 have landed (this wave's pieces)
