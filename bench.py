@@ -270,6 +270,11 @@ def main():
             watchdog = threading.Timer(args.e2e_timeout, give_up)
             watchdog.daemon = True
             watchdog.start()
+        else:                                         # a rank stuck in a collective whose peers gave up must not keep the launcher waiting
+            import threading
+            watchdog = threading.Timer(args.e2e_timeout + 15.0, lambda: os._exit(0))
+            watchdog.daemon = True
+            watchdog.start()
         try:
             del queries
             ctx = bench_e2e.setup(args, rank, world, index=index, topk=k)
