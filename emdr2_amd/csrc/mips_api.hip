@@ -57,7 +57,7 @@ size_t carve(char *base, int dim, Workspace *w)
     char *a = take((size_t)(dim / 32) * 512 * 64);
     char *b = take(512 * sizeof(float));
     char *c = take(512 * sizeof(float));
-    char *d = take(512 * sizeof(unsigned));
+    char *d = take((512 + 8 * (size_t)SCAN8_PROG_UINTS) * sizeof(unsigned));       // per-query candidate counts + pair progress counters of up to 8 scan8 launches
     char *e = take((size_t)512 * CAPQ * sizeof(uint2));
     if (w) { w->q_frag = f; w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; }
     return off;
@@ -177,6 +177,14 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         sp.tune = env_int("EMDR2_MIPS_TUNE", 17);
         sp.trace = (unsigned long long *)w.cand + (size_t)511 * CAPQ; // scratch tail of the candidate area (ABL 9 only)
 
+        unsigned *const prog0 = w.count + 512;
+        int scan8_launches = 0;
+#ifdef EMDR2_EXPERIMENTS
+        const bool couple = env_int("EMDR2_MIPS_COUPLE", 1) != 0;
+#else
+        const bool couple = true;
+#endif
+        if (variant == 0 && hipMemsetAsync(prog0, 0, 8 * (size_t)SCAN8_PROG_UINTS * sizeof(unsigned), stream) != hipSuccess) return EMDR2_E_LAUNCH;
         int64_t done = 0, seg_end = dense_rows;
         int64_t next_boundary = (int64_t)seg0 * growth;
         int mode = 1;
@@ -208,7 +216,11 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
 #endif
             {
                 rc = -4;
-                if (mode == 0 && variant <= 1 && scan_kernel == 1) rc = mips_launch_scan8(sp, BN, done, seg_end, cus, stream);
+                if (mode == 0 && variant <= 1 && scan_kernel == 1) {
+                    unsigned *prog = (couple && scan8_launches < 8) ? prog0 + (size_t)SCAN8_PROG_UINTS * scan8_launches : nullptr;
+                    rc = mips_launch_scan8(sp, BN, done, seg_end, cus, prog, stream);
+                    if (rc == 0) ++scan8_launches;
+                }
                 if (rc == -4) rc = mips_launch_scan(variant, mode, sp, grid, stream);
             }
             if (rc) return rc;

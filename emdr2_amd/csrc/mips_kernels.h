@@ -26,7 +26,9 @@ struct ScanParams {
 // variant: 0 = 128 rows x 512 queries, 1 = 256 x 256, 2 = 512 x 128 ; mode: see mips_scan.hip
 int mips_launch_scan(int variant, int mode, const ScanParams &p, int grid, hipStream_t stream);
 // production filter scan (mode 0) for 256- / 512-row query images in the persistent-GEMM pipeline (mips_scan8.hip); -4 = not covered
-int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, hipStream_t stream);
+// `prog`: SCAN8_PROG_UINTS zeroed uints per launch (pair progress counters, one 256-byte line each) or nullptr
+#define SCAN8_PROG_UINTS (256 * 64)
+int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, unsigned *prog, hipStream_t stream);
 // production filter scan, ping-pong wave schedule (mode 0 only)
 int mips_launch_scan_pp(int variant, int depth, const ScanParams &p, int grid, hipStream_t stream);
 // production filter scan for 512 queries, query operand streamed straight to registers (mode 0, variant 0 only)

@@ -34,6 +34,7 @@ struct Scan8Params {
     int bn;                       // rows of the query image (256 or 512)
     int last_stripe;              // highest 128-row stripe that exists
     int total, per;               // items, items per XCD
+    unsigned *prog;               // progress counters, one per pair of workgroups that share row tiles, 64 uints apart (zeroed by the caller), or nullptr
 };
 
 __device__ __forceinline__ void s8_flush(const ScanParams &p, const char *qbuf, unsigned n, int tid)
@@ -67,7 +68,8 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     if (first >= seq_hi) return;
     const int my_count = (seq_hi - first + wg_per_xcd - 1) / wg_per_xcd;
     const int KT = p.nch >> 1;                                // K-tiles of 64 = pairs of 32-wide chunks; even (host)
-    if (tid == 0) *qcnt = 0;
+    unsigned *const flagw = qcnt + 4;                          // LDS landing word of the partner-progress DMA
+    if (tid == 0) { *qcnt = 0; *flagw = 0; }
     // the workgroups of an XCD stride the sequence by an even count (host) and `per` is even: a workgroup keeps ONE query half for all its items,
     // so its thresholds are loaded once (a load in the filter would wait out the whole DMA queue: vmcnt is in order)
     const int hq = P.halves == 2 ? first & 1 : 0;
@@ -171,6 +173,26 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         }                                                                                                                                 \
     } while (0)
 
+    // ---- partner coupling.  The two workgroups that take the two query halves of the same row tiles (slots 2j, 2j + 1 of one XCD) should read
+    // the index rows within the L2's residency of each other (~10 us of streaming); nothing else couples them (a miss does not slow the
+    // leader down), and uncoupled they drift apart until every row tile is fetched from the fabric twice.  Once per two K-tiles wave 0 adds 1
+    // to the pair's counter (no-return atomic) and has the counter DMA'd into an LDS word (no VGPR result, nothing to wait for); the word
+    // read one round later gives the partner's progress as of ~4 us ago, and a workgroup that leads by two rounds or more naps in
+    // proportion.  The follower never waits, so there is no way to deadlock; a finished workgroup adds 2^20.
+    unsigned *const prog = (P.prog && P.halves == 2) ? P.prog + (xcd * (wg_per_xcd >> 1) + (slot >> 1)) * 64 : nullptr;      // 256 B apart: one L2 line each
+    int ticks = 0;
+#define S8_COUPLE()                                                                                                                       \
+    if (prog && wave == 0) {                                                                                                              \
+        const int tot_ = __builtin_amdgcn_readfirstlane((int)*(volatile __attribute__((address_space(3))) unsigned *)flagw);               \
+        if (lane == 0) {                                                                                                                  \
+            atomicAdd(prog, 1u);                                                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t *)prog, (lptr_t *)flagw, 4, 0, 16);      /* sc1 = agent scope: never from the CU's own L1 */   \
+        }                                                                                                                                 \
+        const int lead_ = 2 * ticks - tot_;                   /* my rounds minus the partner's, both as of the previous round */           \
+        ++ticks;                                                                                                                          \
+        if (!(P.s.tune & 64)) for (int i_ = 0; i_ < (lead_ > 6 ? 6 : lead_) - 1; ++i_) __builtin_amdgcn_s_sleep(16);     /* 1,024 cycles each */ \
+    }
+
     floatx16 acc[4][2];
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
@@ -227,6 +249,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
             S8_BARRIER();
             S8_STAGE(1, 1);
             S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));
+            S8_COUPLE();
             if (kt2 + 2 < KT) { S8_BARRIER(); }
         }
         // ---- item seam.  The leading half is past its last MFMAs one barrier interval before the trailing half: it takes the closing barrier of
@@ -288,6 +311,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         }
     }
     if (wr == 0) { S8_BARRIER(); }                            // the leading half pays back the barrier the trailing half took at the start
+    if (prog && tid == 0) atomicAdd(prog, 1u << 20);          // done: the partner stops pacing itself against this workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // speculative half-tiles past the end of the stream
     S8_BARRIER();
     s8_flush(p, qbuf, *(volatile __attribute__((address_space(3))) unsigned *)qcnt, tid);
@@ -296,11 +320,12 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
 } // namespace
 
 // Filter scan (mode 0) of rows [row_begin, row_end) for a query image of `bn` = 256 or 512 rows; -4 = not covered (the caller uses mips_scan.hip)
-int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, hipStream_t stream)
+int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, unsigned *prog, hipStream_t stream)
 {
     if ((bn != 256 && bn != 512) || (p.nch & 3) || p.nch < 4 || (row_begin & 255) || row_end <= row_begin) return -4;
     Scan8Params P;
     P.s = p;
+    P.prog = prog;
     P.bn = bn; P.halves = bn / 256;
     P.t_begin = (int)(row_begin >> 8);
     P.t_end = (int)((row_end + 255) >> 8);

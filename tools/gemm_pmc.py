@@ -59,22 +59,23 @@ def run():
 def summarize(dirs, shapes_json, out):
     per = [dict(kind=k, M=M, N=N, K=Kd, epilogue=e, counters={}) for k, M, N, Kd, e in CONFIGS]
     for d in dirs:
-        kt = glob.glob(os.path.join(d, "*", "*kernel_trace.csv"))
         cc = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
-        if not kt or not cc:
+        if not cc:
             continue
-        disp = [r for r in csv.DictReader(open(kt[0])) if "gemm8" in r["Kernel_Name"]]
-        disp.sort(key=lambda r: int(r["Start_Timestamp"]))
-        assert len(disp) == len(CONFIGS) * LAUNCHES, (d, len(disp))
-        ctr = collections.defaultdict(dict)
-        for r in csv.DictReader(open(cc[0])):
+        # counter_collection.csv alone (kernel name, timestamps, one row per dispatch and counter): its dispatch ids are not the kernel trace's
+        rows = [r for r in csv.DictReader(open(cc[0])) if "gemm8" in r["Kernel_Name"]]
+        order, ctr = [], collections.defaultdict(dict)
+        for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
+            if r["Dispatch_Id"] not in ctr:
+                order.append((r["Dispatch_Id"], (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
             ctr[r["Dispatch_Id"]][r["Counter_Name"]] = float(r["Counter_Value"])
+        assert len(order) == len(CONFIGS) * LAUNCHES, (d, len(order))
         for i, cfg in enumerate(per):
-            mine = disp[i * LAUNCHES:(i + 1) * LAUNCHES]
-            cfg.setdefault("_dur", []).extend((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6 for r in mine)
-            names = set().union(*(ctr[r["Dispatch_Id"]].keys() for r in mine))
+            mine = order[i * LAUNCHES:(i + 1) * LAUNCHES]
+            cfg.setdefault("_dur", []).extend(ms for _, ms in mine)
+            names = set().union(*(ctr[k].keys() for k, _ in mine))
             for n in names:
-                v = [ctr[r["Dispatch_Id"]][n] for r in mine if n in ctr[r["Dispatch_Id"]]]
+                v = [ctr[k][n] for k, _ in mine if n in ctr[k]]
                 cfg["counters"][n] = sum(v) / len(v)
     for cfg in per:
         dur = cfg.pop("_dur", [])

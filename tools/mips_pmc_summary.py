@@ -10,18 +10,17 @@ out = args[args.index("--out") + 1]
 dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] != "--out")]
 res = {"kernel": None}
 for d in dirs:
-    kt = list(csv.DictReader(open(glob.glob(os.path.join(d, "*", "*kernel_trace.csv"))[0])))
-    scan = [r for r in kt if "mips_scan" in r["Kernel_Name"]]
+    # counter_collection.csv carries kernel name, timestamps and one row per (dispatch, counter); its dispatch ids are NOT the kernel trace's
+    cc = list(csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])))
+    scan = [r for r in cc if "mips_scan" in r["Kernel_Name"]]
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in scan}
     cut = 0.5 * max(dur.values())
     big = [r for r in scan if dur[r["Dispatch_Id"]] > cut]                  # the last-segment launches
     res["kernel"] = big[0]["Kernel_Name"][:80]
-    ns = [dur[r["Dispatch_Id"]] for r in big]
-    res.setdefault("scan_last_segment_launch_ns", {"n": len(ns), "avg": sum(ns) / len(ns), "min": min(ns), "max": max(ns)})
-    ids = set(r["Dispatch_Id"] for r in big)
-    for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])):
-        if r["Dispatch_Id"] in ids:
-            res.setdefault(r["Counter_Name"] + "_KB_last_segment_launch", []).append(float(r["Counter_Value"]))
+    ns = sorted(set((r["Dispatch_Id"], dur[r["Dispatch_Id"]]) for r in big))
+    res.setdefault("scan_last_segment_launch_ns", {"n": len(ns), "avg": sum(v for _, v in ns) / len(ns), "min": min(v for _, v in ns), "max": max(v for _, v in ns)})
+    for r in big:
+        res.setdefault(r["Counter_Name"] + "_KB_last_segment_launch", []).append(float(r["Counter_Value"]))
 rows, nq, dim = 18918172, 512, 768
 res["algorithmic_bytes_last_segment"] = rows * dim * 2          # the index rows of the segment, each read once
 f = res.get("FETCH_SIZE_KB_last_segment_launch"); w = res.get("WRITE_SIZE_KB_last_segment_launch")
