@@ -441,7 +441,12 @@ int g8_launch(G8Params &p, hipStream_t stream)
     const long long panel = 256ll * p.K * 2;
     int ng = (int)(2560ll * 1024 / panel);
     if (ng < 1) ng = 1;
-    if (ng > p.tiles_n || 2 * ng < p.tiles_n || (long long)p.N * p.K * 2 <= (4ll << 20)) ng = p.tiles_n;
+    long long single_kb = 4096;                               // a B matrix up to this size is walked as ONE group (plain n-fastest)
+#ifdef EMDR2_EXPERIMENTS
+    static const int single_env = getenv("EMDR2_G8_SINGLE_KB") ? atoi(getenv("EMDR2_G8_SINGLE_KB")) : 0;
+    if (single_env > 0) single_kb = single_env;
+#endif
+    if (ng > p.tiles_n || 2 * ng < p.tiles_n || (long long)p.N * p.K * 2 <= (single_kb << 10)) ng = p.tiles_n;
     const int groups = (p.tiles_n + ng - 1) / ng;
     p.ngroup = (p.tiles_n + groups - 1) / groups;
     auto magic = [](long long d) { return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d); };

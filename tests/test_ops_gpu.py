@@ -255,6 +255,31 @@ def test_weight_gradient_gemm_tn_with_bias_gradient(M, N, Kd):
     assert torch.allclose(db, dy.float().sum(0), rtol=1e-3, atol=1e-3 * (M ** 0.5))
 
 
+def test_weight_gradient_gemm_tn_strided_operands_and_single_slice():
+    """The persistent TN GEMM (csrc/gemm8t.hip) on column slices of wider activation matrices (lda, ldb > I, J: the packed QKV gradient is
+    consumed like this), written into a column slice of a wider fp32 output, with one reduction slice (plain stores) and with many (atomics)."""
+    from emdr2_amd import _native
+    lib = _native.lib()
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, NF, KF, I, J = 6144, 1024, 1280, 520, 776
+    dy_full = torch.randn((M, NF), generator=g, device="cuda").bfloat16()
+    x_full = torch.randn((M, KF), generator=g, device="cuda").bfloat16()
+    dy, x = dy_full[:, 256:256 + I], x_full[:, 8:8 + J]
+    ref = dy.float().T @ x.float()
+    for split in (1, 7):
+        out = torch.full((I, 1024), 7.0, device="cuda")
+        c = out[:, 128:128 + J]
+        if split > 1:
+            c.zero_()
+        colsum = torch.zeros(I, device="cuda")
+        rc = lib.emdr2_gemm_tn_bf16(dy.data_ptr(), NF, x.data_ptr(), KF, c.data_ptr(), 1024, I, J, M, split, colsum.data_ptr(), None)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert torch.allclose(c, ref, rtol=2e-3, atol=2e-3 * (M ** 0.5))
+        assert torch.allclose(colsum, dy.float().sum(0), rtol=1e-3, atol=1e-3 * (M ** 0.5))
+        assert float(out[:, :128].min()) == 7.0 and float(out[:, 128 + J:].min()) == 7.0 and float(out[:, :128].max()) == 7.0      # nothing outside the slice
+
+
 def test_gelu_epilogue_accuracy_vs_exact_erf():
     """The epilogue's erf (Abramowitz-Stegun 7.1.26, |err| <= 1.5e-7) against torch's exact-erf GELU in fp32: identity GEMM passes x through."""
     x = torch.linspace(-12.0, 12.0, 256 * 256, device="cuda").reshape(256, 256).bfloat16()
