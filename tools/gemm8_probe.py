@@ -6,6 +6,8 @@ import torch
 from emdr2_amd import _native
 if "--exp" in sys.argv:
     _native.LIB_PATH = _native.LIB_PATH.replace("libemdr2_hip.so", "libemdr2_hip_exp.so")
+if "--lib" in sys.argv:                                   # any other build of the library (A/B experiments)
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 from emdr2_amd.model import kernels as K
 
 def bench(fn, flops, name, reps=8):
