@@ -87,11 +87,12 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
     const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
     const int nblk = (p.sk + KB - 1) / KB;
-    auto issue = [&](int blk, int stage) {                                     // sk % 64 == 0 (checked on the host)
+    auto issue = [&](int blk, int stage) {                                     // sk % 32 == 0 (checked on the host)
         char *sb = smem + stage * 16384;
 #pragma unroll
         for (int i = 0; i < 8 / NW; ++i) {
-            const long long key = blk * KB + prow + 8 * NW * i;
+            long long key = blk * KB + prow + 8 * NW * i;
+            if (key >= p.sk) key = p.sk - 1;                                       // the half block past sk (sk % 64 == 32): re-read, masked below
             __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + NW * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
         }
@@ -99,7 +100,8 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     uint32_t vtr[2][2];
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
     for (int blk = wave; blk < nblk; blk += NW) {
-        const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * KB + lane] != 0);
+        const int key = blk * KB + lane;
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
 
@@ -139,6 +141,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
         for (int j = 0; j < 2; ++j) {                                             // two 32-key online-softmax steps per staged block
             const uint32_t km = (uint32_t)(kmask >> (32 * j));
             const int kb0 = key0 + 32 * j;
+            if (kb0 >= p.sk) continue;                                            // sk % 64 == 32: the second half of the last block does not exist
             if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
                 __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
                 continue;
@@ -256,7 +259,7 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
                                    int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream)
 {
     if (!q || !k || !v || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
+    if (head_dim != 64 || sk < 32 || (sk & 31) || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7) || drop_p < 0.f || drop_p >= 1.f) return -1;
     AttnParams p;
     p.q = (const char *)q; p.k = (const char *)k; p.v = (const char *)v; p.o = (char *)o;

@@ -95,18 +95,20 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;
     const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = p.sk / 64;
+    const int nblk = (p.sk + 63) / 64;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
         for (int i = 0; i < 8 / BNW; ++i) {
-            const long long key = blk * 64 + prow + 8 * BNW * i;
+            long long key = blk * 64 + prow + 8 * BNW * i;
+            if (key >= p.sk) key = p.sk - 1;                                       // the half block past sk (sk % 64 == 32): re-read, masked below
             __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
         }
     };
     for (int blk = wave; blk < nblk; blk += BNW) {
-        const unsigned long long w = __builtin_amdgcn_ballot_w64(p.ids_k[(long long)b * p.sk + blk * 64 + lane] != 0);
+        const int key = blk * 64 + lane;
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
     uint32_t ktr[2][2];
@@ -138,7 +140,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         for (int j = 0; j < 2; ++j) {                                             // two 32-key steps per staged block
             const uint32_t km = (uint32_t)(kmask >> (32 * j));
             const int kb0 = key0 + 32 * j;
-            if (km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
+            if (kb0 >= p.sk || km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             const int krow = j * 32 + l31;
             floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(BNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     if (!attn_decode(blockIdx.x, (p.sk + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, kblk, b, n)) return;
     const int k0 = kblk * (BNW * 32) + wave * 32;
     const int key = k0 + l31;
-    const bool wave_live = k0 < p.sk;                                   // sk % 64 == 0: a wave's 32 keys are all valid or all out of range
+    const bool wave_live = k0 < p.sk;                                   // sk % 32 == 0: a wave's 32 keys are all valid or all out of range
     const int kc = wave_live ? key : p.sk - 1;
 
     bf16x8 kf[4], vf[4];
@@ -403,7 +405,7 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
                                    int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
 {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (head_dim != 64 || sk < 64 || (sk & 63) || sk > 65536) return -4;
+    if (head_dim != 64 || sk < 32 || (sk & 31) || sk > 65536) return -4;
     const int64_t strides[13] = {q_sb, q_ss, q_sn, k_sb, k_ss, k_sn, v_sb, v_ss, v_sn, dq_sb, dq_ss, dkv_sb, dkv_ss};
     for (int i = 0; i < 13; ++i)
         if (strides[i] & 7) return -4;

@@ -378,7 +378,7 @@ class AttentionCoreFn(torch.autograd.Function):
     Inputs are the projection outputs themselves: self-attention passes `qsrc` = the packed [b, s, 3, np, hn] QKV tensor (kvsrc None),
     cross-attention `qsrc` = [b, sq, np, hn] and `kvsrc` = the packed [b, sk, 2, np, hn] KV tensor.  The kernels read q, k, v as strided
     slices and the backward writes dq, dk, dv straight into ONE packed gradient (no select_backward zero-fill + add chains).
-    Masks come from token ids (pad id 0) + optional history mask.  hn == 64 and sk % 64 == 0 run the fused kernels (attention.hip,
+    Masks come from token ids (pad id 0) + optional history mask.  hn == 64 and sk % 32 == 0 run the fused kernels (attention.hip,
     attention_bwd.hip); other shapes run QK^T GEMM + softmax kernel + PV GEMM.  Only the row statistics (max, sum-exp) and the output are
     kept; the backward rebuilds the probabilities from them."""
 
@@ -406,7 +406,7 @@ class AttentionCoreFn(torch.autograd.Function):
         m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
         ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
-        if hn == 64 and sk % 64 == 0 and sk <= 65536:
+        if hn == 64 and sk % 32 == 0 and sk <= 65536:
             _native.check(_lib().emdr2_attention_fwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
                                                      k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq,
                                                      sk, hn, int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), _sp()),
@@ -445,7 +445,7 @@ class AttentionCoreFn(torch.autograd.Function):
         H = heads * hn
         lib = _lib()
         D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
-        if hn == 64 and sk % 64 == 0 and sk <= 65536:                                     # fused: no [sq, sk] matrix, no operand transposes
+        if hn == 64 and sk % 32 == 0 and sk <= 65536:                                     # fused: no [sq, sk] matrix, no operand transposes
             _native.check(lib.emdr2_attention_bwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
                                                   k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), dctx.data_ptr(),
                                                   dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dv.data_ptr(), dk.stride(0),

@@ -168,9 +168,11 @@ def _attention_case(b, heads, sq, sk, causal, drop_p, seed, gen_seed):
 
 
 @pytest.mark.parametrize("b,heads,sq,sk,causal", [(3, 4, 64, 64, False), (2, 3, 512, 512, False), (2, 2, 256, 256, True), (3, 2, 32, 1024, False),
-                                                  (2, 2, 288, 320, False), (2, 2, 32, 32, True), (2, 2, 96, 96, False), (2, 2, 32, 25600, False)])
+                                                  (2, 2, 288, 320, False), (2, 2, 32, 32, True), (2, 2, 96, 96, False), (2, 2, 32, 25600, False),
+                                                  (5, 3, 32, 32, False), (2, 2, 96, 96, True), (3, 2, 40, 160, False), (2, 12, 32, 32, True)])
 def test_attention_core_forward_backward_vs_torch(b, heads, sq, sk, causal):
-    """Fused kernel (sk % 64 == 0) and the GEMM + softmax composition (the rest) against fp32 torch, forward and q/k/v gradients."""
+    """Fused kernel (sk % 32 == 0: the decoder's 32 x 32 causal self-attention included) and the GEMM + softmax composition (the rest) against
+    fp32 torch, forward and q/k/v gradients."""
     _attention_case(b, heads, sq, sk, causal, 0.0, 0, 100 + sq + sk)
 
 
