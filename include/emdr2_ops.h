@@ -72,7 +72,7 @@ int emdr2_softmax_mask_bwd(const void *probs, void *dprobs, const int64_t *ids_q
 int emdr2_softmax_mask_t(void *scores_t, void *dprobs_t, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l,
                          const float *d, int batch, int heads, int sq, int sk, int causal, float drop_p, uint32_t seed, void *stream);
 
-/* Fused attention forward for head_dim 64, sk % 64 == 0 (transformer.py:283-381 without the [sq, sk] score matrix): o = dropout(softmax(mask(q k^T
+/* Fused attention forward for head_dim 64, sk % 32 == 0 (transformer.py:283-381 without the [sq, sk] score matrix): o = dropout(softmax(mask(q k^T
  * scale))) v.  q [b, sq, heads, 64] / k [b, sk, heads, 64] strided views (element strides: batch, sequence, head; last dim contiguous),
  * v likewise, o [b, sq, heads, 64] contiguous, masks from token ids (pad id 0) + causal, masked scores REPLACED by -10000.
  * m / l (row max and row sum of exp, fp32 [b, heads, sq]) feed the backward.  Dropout keep-bit = keep(seed, row (b*heads+n)*sq+q,

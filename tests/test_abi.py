@@ -86,9 +86,9 @@ def test_ops_entry_points_validate_arguments_without_a_gpu(lib):
     assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 2, 0, 1, 0.0, 0, None) == -1
     assert lib.emdr2_gemm_tn_bf16(one, 64, one, 64, one, 64, 64, 64, 48, 1, None, None) == -1      # R % 32
     assert lib.emdr2_gemm_tn_bf16(None, 64, one, 64, one, 64, 64, 64, 64, 1, None, None) == -1
-    # attention: head dim 64 and sk % 64 == 0 only (-4 = unsupported shape, the caller falls back to the composed path)
+    # attention: head dim 64 and sk % 32 == 0 only (-4 = unsupported shape, the caller falls back to the composed path)
     args_f = (one, 64, 64, 64, one, 64, 64, 64, one, 64, 64, 64, one, one, one, 1, 1, 32)
-    assert lib.emdr2_attention_fwd(*args_f, 96, 64, 0, 0.125, 0.0, 0, None, None, None) == -4
+    assert lib.emdr2_attention_fwd(*args_f, 72, 64, 0, 0.125, 0.0, 0, None, None, None) == -4
     assert lib.emdr2_attention_fwd(*args_f, 128, 32, 0, 0.125, 0.0, 0, None, None, None) == -4
     assert lib.emdr2_attention_fwd(*args_f, 128, 64, 0, 0.125, 1.5, 0, None, None, None) == -1
     assert lib.emdr2_dropout(one, one, 64, 12, 0.1, 1, None) == -1          # cols % 8
