@@ -16,6 +16,7 @@
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <type_traits>
 #include "rng.h"
 
 #include "attention_common.h"
@@ -145,26 +146,63 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
             if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
                 __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
                 continue;
-            floatx16 sacc;
+            // The rest of the step is instantiated three times (padded wave / masks needed / mask-free) instead of branching inside one body:
+            // a join after the score section made the compiler copy the 16 score registers (and, for the padded path, the 32 of O) at
+            // every step to reconcile the register assignments of the paths.
+            auto dropout_and_pv = [&](floatx16 &sacc) {
+                if (DROP) {                                                       // attention dropout after the normaliser (l is un-dropped)
+                    const uint32_t prod0 = ((uint32_t)(kb0 + 4 * hi) >> 1) * EMDR2_PAIR_MUL;
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const uint32_t b0 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g) * EMDR2_PAIR_MUL);
+                        const uint32_t b1 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g + 1) * EMDR2_PAIR_MUL);
+                        sacc[4 * g] = (b0 & 0xffffu) >= thr ? sacc[4 * g] : 0.f; // (the 1 / (1 - p) of the survivors is applied once, to O)
+                        sacc[4 * g + 1] = (b0 >> 16) >= thr ? sacc[4 * g + 1] : 0.f;
+                        sacc[4 * g + 2] = (b1 & 0xffffu) >= thr ? sacc[4 * g + 2] : 0.f;
+                        sacc[4 * g + 3] = (b1 >> 16) >= thr ? sacc[4 * g + 3] : 0.f;
+                    }
+                }
+                // ---- O^T += V^T P^T : 2 d sub-blocks x 2 k-steps (16 keys each: registers 8w..8w+7) -----------------------------
+#pragma unroll
+                for (int w2 = 0; w2 < 2; ++w2) {
+                    uint32_t pw[4];
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) pw[w] = pack_bf16(sacc[w2 * 8 + 2 * w], sacc[w2 * 8 + 2 * w + 1]);
+                    const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
+                    // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile, u = 2j + w2) by transpose reads
+                    bf16x8 vt0, vt1;
+                    if (j == 0 && w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 0);
+                    else if (j == 0) TR_FRAG2(vt0, av0, vt1, av1, 1);
+                    else if (w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 2);
+                    else TR_FRAG2(vt0, av0, vt1, av1, 3);
+                    oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, pf, oacc[0], 0, 0, 0);
+                    oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
+                }
+            };
             if (all_qpad) {
                 // Every score of this wave is the mask value -10000: the softmax is uniform over ALL keys.  Same numbers as the general
                 // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
+                floatx16 sacc;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sacc[r] = 1.f;
                 mrun = MASKED2;
                 lrun += 32.f;
-            } else {
-                // ---- S^T = K Q^T : 32 keys x 4 k-steps ---------------------------------------------------------------------------
-                const int krow = j * 32 + l31;
-                const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C operand: no v_mov per register
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
+                dropout_and_pv(sacc);
+                continue;
+            }
+            // ---- S^T = K Q^T : 32 keys x 4 k-steps -------------------------------------------------------------------------------
+            const int krow = j * 32 + l31;
+            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C operand: no v_mov per register
+            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
 #pragma unroll
-                for (int t = 1; t < 4; ++t)
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
-                // ---- mask, online softmax (this lane: one query, 16 of the 32 keys; its half-wave partner holds the other 16) ----
-                const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0);   // wave-uniform
+            for (int t = 1; t < 4; ++t)
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
+            // ---- mask, online softmax (this lane: one query, 16 of the 32 keys; its half-wave partner holds the other 16) --------
+            const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0);   // wave-uniform
+            auto softmax_step = [&](auto masks) {
+                constexpr bool MASKS = decltype(masks)::value;
                 float bmax, bsum = 0.f;
-                if (!need_mask) {
+                if (!MASKS) {
                     float mx = sacc[0];
 #pragma unroll
                     for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
@@ -181,54 +219,34 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                     }
                 }
                 bmax = half_max(bmax);
-                const float mnew = fmaxf(mrun, bmax);
-                if (!need_mask) {
-                    const float off = c_q - mnew;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc_q, off)); sacc[r] = e; bsum += e; }
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[r] - mnew); sacc[r] = e; bsum += e; }
-                }
-                bsum = half_sum(bsum);
-                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                lrun = lrun * alpha + bsum;
-                if (__builtin_amdgcn_ballot_w64(mnew != mrun) != 0ull) {         // the running max moved for some query of this wave
+                // LAZY running max: the reference point of the exponentials only moves when some query's block max exceeds it by more than
+                // 2^8 -- with 32 queries per wave the exact max moves in almost every step (and each move costs a rescale of the 32 O
+                // registers: 3 of 10 VALU slots per score), a jump of 8 happens in the first step and then practically never.  Until then
+                // exp2(s - m) <= 256: nothing for fp32 sums or bf16 probabilities (same relative precision), and O / l is unchanged
+                // mathematically; (m, l) stay consistent for the backward, which only ever uses m + log2 l.
+                if (__builtin_amdgcn_ballot_w64(bmax > mrun + 8.f) != 0ull) {
+                    const float mnew = fmaxf(mrun, bmax);
+                    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                    lrun *= alpha;
 #pragma unroll
                     for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) oacc[jj][r] *= alpha;
+                    mrun = mnew;
                 }
-                mrun = mnew;
-            }
-            if (DROP) {                                                           // attention dropout after the normaliser (l is un-dropped)
-                const uint32_t prod0 = ((uint32_t)(kb0 + 4 * hi) >> 1) * EMDR2_PAIR_MUL;
+                if (!MASKS) {
+                    const float off = c_q - mrun;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const uint32_t b0 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g) * EMDR2_PAIR_MUL);
-                    const uint32_t b1 = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(4 * g + 1) * EMDR2_PAIR_MUL);
-                    sacc[4 * g] = (b0 & 0xffffu) >= thr ? sacc[4 * g] : 0.f;     // (the 1 / (1 - p) of the survivors is applied once, to O)
-                    sacc[4 * g + 1] = (b0 >> 16) >= thr ? sacc[4 * g + 1] : 0.f;
-                    sacc[4 * g + 2] = (b1 & 0xffffu) >= thr ? sacc[4 * g + 2] : 0.f;
-                    sacc[4 * g + 3] = (b1 >> 16) >= thr ? sacc[4 * g + 3] : 0.f;
+                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc_q, off)); sacc[r] = e; bsum += e; }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[r] - mrun); sacc[r] = e; bsum += e; }
                 }
-            }
-            // ---- O^T += V^T P^T : 2 d sub-blocks x 2 k-steps (16 keys each: registers 8w..8w+7) ---------------------------------
-#pragma unroll
-            for (int w2 = 0; w2 < 2; ++w2) {
-                uint32_t pw[4];
-#pragma unroll
-                for (int w = 0; w < 4; ++w) pw[w] = pack_bf16(sacc[w2 * 8 + 2 * w], sacc[w2 * 8 + 2 * w + 1]);
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[0], pw[1], pw[2], pw[3]));
-                // V^T fragments for the same key subset (rows 16u + 4*half + {0..3, 8..11} of the V tile, u = 2j + w2) by transpose reads
-                bf16x8 vt0, vt1;
-                if (j == 0 && w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 0);
-                else if (j == 0) TR_FRAG2(vt0, av0, vt1, av1, 1);
-                else if (w2 == 0) TR_FRAG2(vt0, av0, vt1, av1, 2);
-                else TR_FRAG2(vt0, av0, vt1, av1, 3);
-                oacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt0, pf, oacc[0], 0, 0, 0);
-                oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
-            }
+                lrun += half_sum(bsum);
+                dropout_and_pv(sacc);
+            };
+            if (need_mask) softmax_step(std::true_type{});
+            else softmax_step(std::false_type{});
         }
     }
 

@@ -79,9 +79,25 @@ def test_incremental_decode_matches_the_oracle_decoder():
 
 
 def test_cached_decode_equals_block_decode():
+    """One position per step through the K/V caches against the block form (whole prefix re-decoded every step).  The two run different
+    attention kernels, so their logits agree to bf16 round-off, not to the bit: while the prefixes agree every step's logits must be within
+    2e-2 of the logit scale, and the sequences may only part where the block form's arg-max margin is inside that band."""
     m, qb, _ = _model_and_inputs()
     inc, li = _decode(m, qb, incremental=True)
     blk, lb = _decode(m, qb, incremental=False)
-    assert inc == blk
-    assert li.shape == lb.shape
-    assert float((li - lb).abs().max()) <= 2e-2 * float(lb.abs().max())
+    steps = min(li.shape[1], lb.shape[1])
+    tol = 2e-2 * float(lb.abs().max())
+    compared = 0
+    for q in range(B):
+        for t in range(steps):
+            assert float((li[q, t] - lb[q, t]).abs().max()) <= tol, (q, t)
+            a, b = int(torch.argmax(li[q, t])), int(torch.argmax(lb[q, t]))
+            if a != b:
+                top2 = torch.topk(lb[q, t], 2).values
+                assert float(top2[0] - top2[1]) <= 2 * tol, (q, t, a, b)      # a near-tie: from here on the prefixes differ
+                break
+            compared += 1
+            if a == EOS:
+                break
+    assert compared >= 4 * B, compared
+    assert sum(x == y for x, y in zip(inc, blk)) >= B // 2                     # and most questions decode identically to the end
