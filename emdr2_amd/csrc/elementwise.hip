@@ -520,6 +520,12 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids
 {
     const long long t = blockIdx.x;
     const long long id = ids[t];
+    // In training, padding positions receive exactly zero gradient (masked as keys everywhere, nothing reads their outputs, every backward
+    // kernel maps zero rows to zero rows) and half of the reader's tokens are padding: adding their zeros to row 0 serialised ~800k atomics
+    // per column on one address.  A row of zeros is skipped whatever its id (adding it changes nothing, so this is exact for any caller).
+    int nz = 0;
+    for (int i = threadIdx.x; i < H; i += 256) nz |= (dout[t * H + i] & 0x7fff) != 0;
+    if (!__syncthreads_or(nz)) return;
     const uint32_t rh = emdr2_row_hash(seed, (unsigned long long)t), thr = emdr2_drop_thr(drop_p);
     const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
     for (int i = threadIdx.x; i < H; i += 256) {
