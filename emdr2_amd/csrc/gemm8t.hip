@@ -6,8 +6,8 @@
 // Reference op: the autograd weight gradient of F.linear (megatron/mpu/layers.py:255,353) = dy^T x, R = 1.6M tokens in the EMDR2 step.
 //
 // What carries over from gemm8.hip: the 256 x 256 output tile held by 8 waves (2 x 4, 128 x 64 outputs = 4 x 2 accumulators each), K-tile = 64
-// reduction rows in two LDS buffers of four 16 KiB half-tiles (A0, B0, B1, A1) re-used half-tile by half-tile, four phases per K-tile with
-// 8 MFMAs each behind one half-tile of LDS-DMA issued six half-tiles ahead (counted vmcnt(8)), the two wave halves one barrier apart.
+// reduction rows as four 16 KiB half-tiles (A0, B0, B1, A1) re-used half-tile by half-tile, four phases per K-tile with 8 MFMAs each behind
+// one half-tile of LDS-DMA and a counted vmcnt, the two wave halves one barrier apart.
 // What differs:
 //  * the operands arrive with the REDUCTION index slow.  A half-tile is [64 r][128 columns]: full 256-byte rows straight from the activation
 //    matrices (one DMA instruction = 4 rows), and the fragments are gathered with ds_read_b64_tr_b16 (two per 8-element k-run, layout as in
@@ -15,9 +15,11 @@
 //    service group touches land on 4 x 64 B = distinct banks.
 //  * a wave's 128 i-columns are two separate blocks of 64 (block h in half-tile A_h), its 64 j-columns two blocks of 32, so that every half-
 //    tile is one contiguous 128-column span of the operand.
+//  * no epilogue staging is needed (the result goes out as fp32 atomics), so all 160 KiB of LDS are operand ring: ten half-tile slots, stages
+//    eight half-tiles ahead, vmcnt(12).
 //  * work item = (reduction slice, output tile), one per workgroup, tile index fastest and an XCD-contiguous item range: the tiles that stream
-//    the same token rows run together on one L2.  The epilogue is 128 fp32 atomics (or plain stores, one slice) per wave once per ~900 K-tiles:
-//    no staging, no persistence needed.
+//    the same token rows run together on one L2; slices are interleaved K-tile by K-tile.  The epilogue is 128 fp32 atomics (or plain stores,
+//    one slice) per wave once per ~900 K-tiles: no persistence needed.
 //  * optional bias gradient: colsum[i] += sum_r A[r, i], from the A fragments of the waves wc == 0 of the tj == 0 tiles (v_dot2_f32_bf16
 //    against ones: four VALU ops per fragment).
 #include "../../include/emdr2_ops.h"
@@ -38,13 +40,13 @@ struct T8Params {
     long long lda, ldb, ldc;
     int I, J;
     int tiles_i, tiles, items;      // items = tiles * slices
-    int slices, total_pairs;        // reduction slices; pairs of K-tiles (2 x 64 reduction rows) in all.  Slice z takes pairs z, z + slices, ...
+    int slices, total_kt;           // reduction slices; K-tiles (64 reduction rows) in all.  Slice z takes K-tiles z, z + slices, ...
     int atomic;                     // more than one slice: accumulate with fp32 atomics into a pre-zeroed C
     int ablate;                     // -DEMDR2_EXPERIMENTS builds only (EMDR2_T8_ABLATE): 1 = the DMA stream re-reads K-tile 0, 2 = no DMA
 };
 
-#define T8_BUF 65536
-#define T8_SLOT 16384
+#define T8_SLOT 16384                 // one half-tile: 64 reduction rows x 128 columns x 2 B
+#define T8_RING (10 * T8_SLOT)        // all 160 KiB of a CU's LDS
 
 __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
 {
@@ -58,13 +60,13 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     // ---- this workgroup's item: XCD x = id & 7 owns items [x * per_xcd, (x + 1) * per_xcd), tile index fastest inside a slice
     const int per_xcd = (p.items + 7) >> 3;
     const int item = ((int)blockIdx.x & 7) * per_xcd + ((int)blockIdx.x >> 3);
-    if ((int)(blockIdx.x >> 3) >= per_xcd || item >= p.items) return;
+    if (item >= p.items) return;
     const int zs = item / p.tiles, tile = item - zs * p.tiles;
     const int tj = tile / p.tiles_i, ti = tile - tj * p.tiles_i;
     const int i0 = ti * 256, j0 = tj * 256;
-    // the slices are INTERLEAVED pair by pair: at any moment all workgroups read one window of `slices` consecutive K-tile pairs (a few MB that
-    // slides down the operands) instead of `slices` streams a hundred MB apart -- DRAM pages and the memory-side cache see one sequential reader
-    const int KT = 2 * ((p.total_pairs - zs + p.slices - 1) / p.slices);                      // >= 2 (host: slices <= total_pairs)
+    // the slices are INTERLEAVED K-tile by K-tile: at any moment all workgroups read one window of `slices` consecutive K-tiles (a few MB that
+    // slides down the operands) instead of `slices` streams a hundred MB apart
+    const int KT = (p.total_kt - zs + p.slices - 1) / p.slices;                               // >= 1 (host: slices <= total_kt)
     const long long lda2 = p.lda * 2, ldb2 = p.ldb * 2;
 
     // ---- LDS-DMA addressing.  A half-tile is 64 LDS rows of 256 B; a DMA instruction writes 4 rows (lane -> row lane >> 4, 16-B slot lane & 15);
@@ -81,32 +83,34 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     }
 #ifdef EMDR2_EXPERIMENTS
     const int zs_addr = p.ablate == 3 ? 0 : zs;               // 3 = every slice streams slice 0's rows (fresh lines, but shared by all)
+    const int KT_STREAM = p.ablate == 1 ? 1 : KT;             // 1 = the DMA stream re-reads its first K-tile (always L2-hot)
+    const bool T8_DMA_ON = p.ablate != 2;                     // 2 = no DMA at all
 #else
     const int zs_addr = zs;
-#endif
-    const char *sA = p.A + (long long)zs_addr * 128 * lda2, *sB = p.B + (long long)zs_addr * 128 * ldb2;
-    const long long hopA = (long long)(2 * p.slices - 1) * 64 * lda2, hopB = (long long)(2 * p.slices - 1) * 64 * ldb2;   // second K-tile of a pair -> next pair
-    int s_kt = 0;
-#ifdef EMDR2_EXPERIMENTS
-    const int KT_STREAM = p.ablate == 1 ? 1 : KT;
-    const bool T8_DMA_ON = p.ablate != 2;
-#else
     const int KT_STREAM = KT;
     constexpr bool T8_DMA_ON = true;
 #endif
-#define T8_STAGE(T, SB)                                                                                                                   \
+    const char *sA = p.A + (long long)zs_addr * 64 * lda2, *sB = p.B + (long long)zs_addr * 64 * ldb2;
+    const long long hopA = (long long)p.slices * 64 * lda2, hopB = (long long)p.slices * 64 * ldb2;
+    int s_kt = 0;
+    // The LDS is a ring of TEN half-tile slots filled in stream order (A0, B0, B1, A1 of K-tile 0, of K-tile 1, ...).  The stage of a phase
+    // goes EIGHT half-tiles ahead of the half-tile that phase consumes, into the slot whose last read was two phases ago; "everything but the
+    // newest six half-tiles has landed" = vmcnt(12) is what the next phase's reads need: six phases of latency cover instead of the four of the
+    // 8-slot ring of gemm8.hip (every operand byte is a fresh HBM line here; measured +2.5 %).  Ring positions are wave-uniform byte offsets:
+    // DMA destinations go through M0, fragment reads add the offset once per fragment column.
+    int st_off = 0;
+#define T8_STAGE(T)                                                                                                                       \
     do {                                                                                                                                  \
         const char *src_ = ((T) == 0 || (T) == 3) ? sA : sB;                                                                              \
         const uint32_t off_ = (T) == 0 ? offA[0] : (T) == 3 ? offA[1] : (T) == 1 ? offB[0] : offB[1];                                     \
         const long long half_ = ((T) == 0 || (T) == 3) ? 32 * lda2 : 32 * ldb2;                                                           \
-        char *dst_ = smem + (SB) * T8_BUF + (T) * T8_SLOT + wave * 1024;                                                                   \
+        char *dst_ = smem + st_off + wave * 1024;                                                                                          \
         if (T8_DMA_ON) {                                                                                                                  \
             __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + off_), (lptr_t *)dst_, 16, 0, 0);                                          \
             __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + half_ + off_), (lptr_t *)(dst_ + 8192), 16, 0, 0);                         \
         }                                                                                                                                 \
-        if ((T) == 3 && s_kt + 1 < KT_STREAM) {          /* past the end: harmless re-reads of the last K-tile */                           \
-            sA += (s_kt & 1) ? hopA : 64 * lda2; sB += (s_kt & 1) ? hopB : 64 * ldb2; ++s_kt;                                             \
-        }                                                                                                                                 \
+        st_off = st_off == T8_RING - T8_SLOT ? 0 : st_off + T8_SLOT;                                                                       \
+        if ((T) == 3 && s_kt + 1 < KT_STREAM) { ++s_kt; sA += hopA; sB += hopB; }   /* past the end: harmless re-reads of the last K-tile */ \
     } while (0)
 
     // ---- transposed fragment reads: lane (t, colgrp, hi) addresses row 8 hi + (t >> 2) (+ 4 for the second read) of a 16-row k-step and the
@@ -123,23 +127,28 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
         b_rd = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
     }
     bf16x8 av[2][4], b0v[4], b1v[4];
-#define T8_FRAG(OFF)                                                                                                                      \
-    __builtin_bit_cast(bf16x8, __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)(smem + (OFF))),                \
-                                                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)(smem + (OFF) + 1024)), 0, 1, 2, 3, 4, 5, 6, 7))
-#define T8_READ_A(BUF, MH)                                                                                                                \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                         \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
-            av[f][ks] = T8_FRAG((BUF) * T8_BUF + ((MH) ? 3 * T8_SLOT : 0) + ks * 4096 + a_rd[f])
-#define T8_READ_B(BUF, NH, DST)                                                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        DST[ks] = T8_FRAG((BUF) * T8_BUF + ((NH) ? 2 * T8_SLOT : T8_SLOT) + ks * 4096 + b_rd)
+    int rd_off = 0;                                           // ring offset of the current K-tile's A0; B0, B1, A1 follow (with wrap-around)
+    auto ring = [](int off) { return off >= T8_RING ? off - T8_RING : off; };
+#define T8_FRAG(BASE, OFF)                                                                                                                \
+    __builtin_bit_cast(bf16x8, __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)((BASE) + (OFF))),              \
+                                                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)((BASE) + (OFF) + 1024)), 0, 1, 2, 3, 4, 5, 6, 7))
+#define T8_READ_A(SLOT)                                                                                                                   \
+    _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                                                                       \
+        const char *base_ = smem + (uint32_t)(ring(rd_off + (SLOT) * T8_SLOT) + (int)a_rd[f]);                                             \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) av[f][ks] = T8_FRAG(base_, ks * 4096);                                           \
+    }
+#define T8_READ_B(SLOT, DST)                                                                                                              \
+    {                                                                                                                                     \
+        const char *base_ = smem + (uint32_t)(ring(rd_off + (SLOT) * T8_SLOT) + (int)b_rd);                                                \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = T8_FRAG(base_, ks * 4096);                                             \
+    }
     // rows of the MFMA result = i (A fragment first), columns = j: a lane holds one j and 16 i, so 32 lanes write 128 contiguous bytes of C
 #define T8_MFMA(MH, NH, BV)                                                                                                               \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
             acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[f][ks], BV[ks], acc[2 * (MH) + f][NH], 0, 0, 0)
 #define T8_SYNC_COMPUTE(MFMAS)                                                                                                            \
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                                      \
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
     __builtin_amdgcn_s_barrier();                                                                                                         \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
@@ -175,55 +184,34 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
             }                                                                                                                             \
     }
 
-    // ---- prologue: the first six half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
-    T8_STAGE(0, 0); T8_STAGE(1, 0); T8_STAGE(2, 0); T8_STAGE(3, 0); T8_STAGE(0, 1); T8_STAGE(1, 1);
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0 of K-tile 0 have landed (this wave's pieces)
+    // ---- prologue: the first eight half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
+    T8_STAGE(0); T8_STAGE(1); T8_STAGE(2); T8_STAGE(3); T8_STAGE(0); T8_STAGE(1); T8_STAGE(2); T8_STAGE(3);
+    asm volatile("s_waitcnt vmcnt(12)" ::: "memory");         // A0, B0 of K-tile 0 have landed (this wave's pieces)
     T8_BARRIER();
     if (wr == 1) { T8_BARRIER(); }
 
-    for (int kt2 = 0; kt2 < KT; kt2 += 2) {
-        // ---- K-tile in buffer 0
-        T8_READ_B(0, 0, b0v); T8_READ_A(0, 0);
+    for (int kt = 0; kt < KT; ++kt) {
+        T8_READ_B(1, b0v); T8_READ_A(0);
         __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(2, 1);
+        T8_STAGE(0);
         T8_SYNC_COMPUTE(T8_MFMA(0, 0, b0v));
         T8_COLSUM(0);
         T8_BARRIER();
-        T8_READ_B(0, 1, b1v);
+        T8_READ_B(2, b1v);
         __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(3, 1);
+        T8_STAGE(1);
         T8_SYNC_COMPUTE(T8_MFMA(0, 1, b1v));
         T8_BARRIER();
-        T8_READ_A(0, 1);
+        T8_READ_A(3);
         __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(0, 0);
+        T8_STAGE(2);
         T8_SYNC_COMPUTE(T8_MFMA(1, 1, b1v));
         T8_COLSUM(1);
         T8_BARRIER();
-        T8_STAGE(1, 0);
+        T8_STAGE(3);
         T8_SYNC_COMPUTE(T8_MFMA(1, 0, b0v));
-        T8_BARRIER();
-        // ---- K-tile in buffer 1
-        T8_READ_B(1, 0, b0v); T8_READ_A(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(2, 0);
-        T8_SYNC_COMPUTE(T8_MFMA(0, 0, b0v));
-        T8_COLSUM(0);
-        T8_BARRIER();
-        T8_READ_B(1, 1, b1v);
-        __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(3, 0);
-        T8_SYNC_COMPUTE(T8_MFMA(0, 1, b1v));
-        T8_BARRIER();
-        T8_READ_A(1, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        T8_STAGE(0, 1);
-        T8_SYNC_COMPUTE(T8_MFMA(1, 1, b1v));
-        T8_COLSUM(1);
-        T8_BARRIER();
-        T8_STAGE(1, 1);
-        T8_SYNC_COMPUTE(T8_MFMA(1, 0, b0v));
-        if (kt2 + 2 < KT) { T8_BARRIER(); }
+        rd_off = ring(rd_off + 4 * T8_SLOT);
+        if (kt + 1 < KT) { T8_BARRIER(); }
     }
     if (wr == 0) { T8_BARRIER(); }                            // the leading half pays back the barrier the trailing half took at the start
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // speculative half-tiles past the end of the stream
@@ -260,19 +248,19 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
 } // namespace
 
 // Called by emdr2_gemm_tn_bf16 (gemm_tn.hip); -4 = shape not covered, the caller falls through to the general kernel.  `split_k` is the number
-// of reduction slices (capped at the number of K-tile pairs).
+// of reduction slices (capped at the number of K-tiles).
 int emdr2_gemm8t_try(const void *A, int64_t lda, const void *B, int64_t ldb, float *C, int64_t ldc, int I, int J, int R, int split_k,
                      float *colsum_a, hipStream_t stream)
 {
-    if ((R & 127) || R < 128 || I < 8 || J < 8 || (I & 7) || (J & 7)) return -4;
+    if ((R & 63) || R < 64 || I < 8 || J < 8 || (I & 7) || (J & 7)) return -4;
     if (40ll * lda * 2 + 2ll * I >= (1ll << 32) || 40ll * ldb * 2 + 2ll * J >= (1ll << 32)) return -4;       // 32-bit lane offsets inside a K-tile
     T8Params p;
     p.A = (const char *)A; p.B = (const char *)B; p.C = C; p.colsum = colsum_a;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.I = I; p.J = J;
     p.tiles_i = (I + 255) / 256;
     p.tiles = p.tiles_i * ((J + 255) / 256);
-    p.total_pairs = R >> 7;
-    p.slices = split_k < p.total_pairs ? split_k : p.total_pairs;
+    p.total_kt = R >> 6;
+    p.slices = split_k < p.total_kt ? split_k : p.total_kt;
     p.items = p.tiles * p.slices;
     p.ablate = 0;
 #ifdef EMDR2_EXPERIMENTS
@@ -280,7 +268,7 @@ int emdr2_gemm8t_try(const void *A, int64_t lda, const void *B, int64_t ldb, flo
     p.ablate = ablate_env;
 #endif
     p.atomic = split_k > 1;                                   // the caller zeroed C exactly when it asked for more than one slice
-    constexpr int LDS = 2 * T8_BUF;
+    constexpr int LDS = T8_RING;
     static bool attr_done = false;
     if (!attr_done) {
         if (hipFuncSetAttribute((const void *)gemm8t_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;

@@ -57,7 +57,7 @@ def main():
     def weight_grad_tn(dy, x, colsum=None):
         M, N = dy.shape
         Kd = x.shape[1]
-        key = ("tn", M, N, Kd, 1, "colsum" if colsum is not None else "plain", "gemm8t_kernel" if M % 128 == 0 else "gemm_tn_kernel")
+        key = ("tn", M, N, Kd, 1, "colsum" if colsum is not None else "plain", "gemm8t_kernel" if M % 64 == 0 else "gemm_tn_kernel")
         return timed(key, 2.0 * M * N * Kd, lambda: tn_raw(dy, x, colsum))
 
     def lm_head_gold_logprob(hidden, weight, bias, labels):
