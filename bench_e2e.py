@@ -49,6 +49,9 @@ def add_args(ap):
     ap.add_argument("--seq", type=int, default=512)
     ap.add_argument("--seq-ret", type=int, default=256)
     ap.add_argument("--dropout", type=float, default=0.1, help="hidden and attention dropout (the reference's default, arguments.py)")
+    ap.add_argument("--keep-last-layers", default="auto",
+                    help="reader-encoder layers whose activations are kept instead of re-run in the backward: a number, or 'auto' = as many as "
+                         "fit the HBM left over after a first full-recompute step with 25 GB to spare (falls back to 0 on an allocation failure)")
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
                     help="BASELINE configs[5]: re-embed this many evidence rows per training step on a side stream into the spare index image "
                          "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
@@ -130,8 +133,28 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(keep_last_arg=getattr(args, "keep_last_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
+
+
+def choose_keep_last(ctx, world):
+    """How many of the last reader-encoder layers keep their activations (transformer.ParallelTransformer.keep_last).  'auto': from the peak
+    of the full-recompute warm-up step.  The first kept layer is free (it replaces the transient of the layer re-run that set the peak), every
+    further one is budgeted at 18 bf16 [tokens, H] tensors (16.3 measured); 25 GB are left to spare.  All ranks take the minimum."""
+    want = getattr(ctx, "keep_last_arg", "auto")
+    if want != "auto":
+        return max(0, min(int(want), ctx.layers))
+    free, total = torch.cuda.mem_get_info()
+    capacity = free + torch.cuda.memory_reserved()            # what this process can have: its own pool + what is still free
+    peak = torch.cuda.max_memory_reserved()
+    per_layer = ctx.B * ctx.K * ctx.S * H * 2 * 18           # measured: 41 GB per kept layer at B = 64, K = 50, S = 512 (16.3 tensors of [tokens, H] bf16)
+    n = int(1 + (capacity - (25 << 30) - peak) // per_layer) if capacity - (25 << 30) > peak else 0
+    n = max(0, min(n, 4, ctx.layers))
+    if world > 1:
+        t = torch.tensor([n], device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
+        n = int(t.item())
+    return n
 
 
 def run(ctx, steps, warmup, world):
@@ -150,6 +173,19 @@ def run(ctx, steps, warmup, world):
     for _ in range(warmup):
         loss = ctx.step()
     fence()
+    keep = choose_keep_last(ctx, world)
+    if keep > 0:                                             # one more untimed step so the allocator has grown before the timed region
+        ctx.model.set_recompute_keep_last(keep)
+        try:
+            loss = ctx.step()
+            warmup += 1
+        except torch.cuda.OutOfMemoryError:                  # the estimate was too optimistic on this box: back to full recompute
+            keep = 0
+            ctx.model.set_recompute_keep_last(0)
+            ctx.opt.zero_grad()
+            torch.cuda.empty_cache()
+        fence()
+    ctx.keep_last = keep
     lib.emdr2_ops_set_timing(1)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -173,7 +209,8 @@ def run(ctx, steps, warmup, world):
         "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
-                   "dropout": ctx.dropout, "activation_recompute": "per layer", "loss": float(loss.detach()),
+                   "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (activations kept in HBM)" % ctx.keep_last if ctx.keep_last else ""),
+                   "loss": float(loss.detach()),
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                    "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
                    "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
@@ -266,7 +303,7 @@ def main():
     ctx = setup(args, rank, world, topk=args.topk)
     res = run(ctx, args.steps, args.warmup, world)
     if rank == 0:
-        out = {"metric": "qa_train_steps_per_sec", "value": res["steps_per_s"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        out = {"metric": "qa_train_steps_per_sec", "value": res["steps_per_s"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": res["warmup"],
                "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic", "config": res["config"], "roofline": res["roofline"]}
         if args.cpu_baseline and world == 1:

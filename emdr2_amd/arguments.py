@@ -27,6 +27,9 @@ def get_parser():
     g = p.add_argument_group('training')
     g.add_argument('--batch-size', type=int, default=None)
     g.add_argument('--checkpoint-activations', action='store_true')
+    g.add_argument('--recompute-keep-last-layers', type=int, default=0,
+                   help='(not in the reference) with --checkpoint-activations: keep the activations of the last N reader-encoder layers '
+                        'instead of re-running them in the backward (~33 GB of HBM per layer at batch 64 x top-k 50 x 512 tokens)')
     g.add_argument('--seed', type=int, default=1234)
     g.add_argument('--init-method-std', type=float, default=0.02)
     g.add_argument('--lr', type=float, default=None)

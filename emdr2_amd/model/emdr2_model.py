@@ -244,6 +244,12 @@ class EMDR2Model(torch.nn.Module):
         checkpointing.load_emdr2_state_dict(self, state, strict)
         K.WEIGHTS.invalidate()
 
+    def set_recompute_keep_last(self, reader_encoder_layers):
+        """Under --checkpoint-activations, keep the activations of the last n reader-encoder layers instead of re-running them in the backward
+        (the reader encoder holds B * K * S tokens: its layers are the expensive ones to re-run).  Gradients are unchanged
+        (tests/test_model_gpu.py); ~33 GB of HBM per layer at B = 64, K = 50, S = 512."""
+        self.language_model.language_model.encoder.keep_last = max(0, int(reader_encoder_layers))
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         """The reference's name for the above (emdr2_model.py:228-231 overrides nn.Module.load_state_dict with the nested form);
         a flat torch state dict still goes to nn.Module."""

@@ -187,10 +187,14 @@ class ParallelTransformer(torch.nn.Module):
         self.layers = torch.nn.ModuleList([ParallelTransformerLayer(cfg, out_std, layer_type) for _ in range(cfg.num_layers)])
         self.final_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
         self.checkpoint_activations = checkpoint_activations
+        # With 288 GB of HBM not every layer has to be re-run in the backward: the LAST `keep_last` layers keep their activations (they are
+        # produced last and consumed first, so they cost the least peak memory per layer kept).  0 = the reference's --checkpoint-activations.
+        self.keep_last = 0
 
     def forward(self, x, ids, causal=False, encoder_output=None, enc_ids=None):
-        for layer in self.layers:
-            if self.checkpoint_activations and torch.is_grad_enabled():
+        n_recompute = len(self.layers) - int(self.keep_last)
+        for li, layer in enumerate(self.layers):
+            if self.checkpoint_activations and torch.is_grad_enabled() and li < n_recompute:
                 # determinism_check off: the first run of a layer deliberately saves placeholders for tensors only its re-run needs (the
                 # FFN pre-activation), so saved-tensor shapes differ between the two runs by design; the COUNT and order stay equal
                 x = torch.utils.checkpoint.checkpoint(_CheckpointedLayer(layer), x, ids, causal, encoder_output, enc_ids, use_reentrant=False,
