@@ -16,6 +16,8 @@
 //    reads and one half-tile of LDS-DMA six half-tiles ahead (vmcnt(8)), the two wave halves one barrier apart, persistent DMA stream across
 //    items: the schedule of gemm8.hip, which the same measurements put at 1,300 TFLOP/s without an output epilogue.
 //  * the epilogue is the filter: per accumulator block a max + one ballot in the common case (no survivor).
+//  * the two workgroups that share a row tile pace themselves against each other through a progress counter (S8_COUPLE below): without it
+//    they drift apart by more than the L2 holds and the index rows are fetched from the fabric 1.77 times; with it 1.015 times.
 // LDS: 128 KiB operand ring + 32 KiB survivor queue.
 #include "mips_device.h"
 #include "mips_kernels.h"
