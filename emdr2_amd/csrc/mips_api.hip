@@ -232,7 +232,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
             if ((rc = mips_launch_select(w.cand, w.count, w.tau, out_flags + q0, CAPQ, kp, nqp, stream))) return rc;
             done = seg_end;
             seg_end = next_boundary < n_rows ? next_boundary : n_rows;
-            if (n_rows - seg_end < seg_end / 4) seg_end = n_rows; // do not leave a sliver for a last launch
+            if (n_rows - seg_end < seg_end / 2) seg_end = n_rows; // do not leave a short tail for a last launch (a launch + a select cost ~70 us)
             next_boundary *= growth;
             mode = 0;
         }
