@@ -80,6 +80,9 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     for (int ni = 0; ni < 2; ++ni) {
         const int q = hq * 256 + wc * 64 + ni * 32 + l31;
         tauv[ni] = q < p.n_q ? p.tau[q] : __builtin_inff();
+#ifdef EMDR2_EXPERIMENTS
+        if (p.tune & 128) tauv[ni] = __builtin_inff();        // timing experiment: the filter never fires
+#endif
     }
 
     // ---- LDS-DMA addressing.  The operand images in HBM are LDS images already (mips_device.h: 64-byte rows, 16-byte groups XOR-swizzled with
@@ -269,34 +272,33 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         for (int ni = 0; ni < 2; ++ni) {
             const unsigned q = (unsigned)(hq * 256 + wc * 64 + ni * 32 + e31);
             const float tau = tauv[ni];
-            float m = acc[0][ni][0];
+            // one max + one ballot per 32 x 32 accumulator block: a survivor sends its wave through the 16 registers of ONE block, not the 64 of a
+            // query column (1.6 survivors per item in the last segment; every slow path holds up the seven other waves at the next barrier)
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 4; ++mi) {
+                float m = acc[mi][ni][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
-            if (__builtin_amdgcn_ballot_w64(m >= tau) != 0) {                      // rare: some (row, query) of this block passes
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                if (__builtin_amdgcn_ballot_w64(m >= tau) == 0) continue;          // the common case
 #pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[mi][ni][r];
-                        const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
-                        const bool pass = (v >= tau) && (row < p.n_rows);
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-                        if (mask == 0) continue;
-                        unsigned base = 0;
-                        if (elane == 0) base = atomicAdd(qcnt, (unsigned)__popcll(mask));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (pass) {
-                            const unsigned slot_ = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            if (slot_ < S8_QCAP) {
-                                ((uint4 *)qbuf)[slot_] = make_uint4(__float_as_uint(v), (unsigned)row, q, 0u);
-                            } else {                                               // queue full: straight to the candidate buffer
-                                const unsigned g = atomicAdd(&p.count[q], 1u);
-                                if (g < p.capq) p.cand[(size_t)q * p.capq + g] = make_uint2(__float_as_uint(v), (unsigned)row);
-                                else atomicOr(&p.flags[q], 2u);
-                                stored = true;
-                            }
+                for (int r = 0; r < 16; ++r) {
+                    const float v = acc[mi][ni][r];
+                    const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
+                    const bool pass = (v >= tau) && (row < p.n_rows);
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                    if (mask == 0) continue;
+                    unsigned base = 0;
+                    if (elane == 0) base = atomicAdd(qcnt, (unsigned)__popcll(mask));
+                    base = __builtin_amdgcn_readfirstlane(base);
+                    if (pass) {
+                        const unsigned slot_ = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (slot_ < S8_QCAP) {
+                            ((uint4 *)qbuf)[slot_] = make_uint4(__float_as_uint(v), (unsigned)row, q, 0u);
+                        } else {                                                   // queue full: straight to the candidate buffer
+                            const unsigned g = atomicAdd(&p.count[q], 1u);
+                            if (g < p.capq) p.cand[(size_t)q * p.capq + g] = make_uint2(__float_as_uint(v), (unsigned)row);
+                            else atomicOr(&p.flags[q], 2u);
+                            stored = true;
                         }
                     }
                 }
