@@ -176,15 +176,14 @@ __global__ void __launch_bounds__(512) mips_scan_kernel(ScanParams p)
             bool stored = false;
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
-                float m = acc[0][ni][0];
-#pragma unroll
-                for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
-                if (__builtin_amdgcn_ballot_w64(m >= tau[ni]) == 0) continue; // the common case
                 const unsigned q = wn * 128 + ni * 32 + l31;
 #pragma unroll
                 for (int mi = 0; mi < 2; ++mi) {
+                    // one max + one ballot per 32 x 32 accumulator block (a survivor costs 16 register checks, not 32)
+                    float m = acc[mi][ni][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                    if (__builtin_amdgcn_ballot_w64(m >= tau[ni]) == 0) continue; // the common case
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const float v = acc[mi][ni][r];
