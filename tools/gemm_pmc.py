@@ -63,7 +63,7 @@ def summarize(dirs, shapes_json, out):
         if not cc:
             continue
         # counter_collection.csv alone (kernel name, timestamps, one row per dispatch and counter): its dispatch ids are not the kernel trace's
-        rows = [r for r in csv.DictReader(open(cc[0])) if "gemm8" in r["Kernel_Name"]]
+        rows = [r for r in csv.DictReader(open(max(cc, key=os.path.getmtime))) if "gemm8" in r["Kernel_Name"]]     # newest run in the directory
         order, ctr = [], collections.defaultdict(dict)
         for r in sorted(rows, key=lambda r: int(r["Start_Timestamp"])):
             if r["Dispatch_Id"] not in ctr:

@@ -11,7 +11,7 @@ dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or a
 res = {"kernel": None}
 for d in dirs:
     # counter_collection.csv carries kernel name, timestamps and one row per (dispatch, counter); its dispatch ids are NOT the kernel trace's
-    cc = list(csv.DictReader(open(glob.glob(os.path.join(d, "*", "*counter_collection.csv"))[0])))
+    cc = list(csv.DictReader(open(max(glob.glob(os.path.join(d, "*", "*counter_collection.csv")), key=os.path.getmtime))))     # newest run in the directory
     scan = [r for r in cc if "mips_scan" in r["Kernel_Name"]]
     dur = {r["Dispatch_Id"]: int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in scan}
     cut = 0.5 * max(dur.values())
