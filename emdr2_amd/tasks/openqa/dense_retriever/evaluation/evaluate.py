@@ -5,7 +5,6 @@ default), and report the fraction of questions with an answer-bearing passage am
 MI355X-native differences: the index is the row-sharded in-HBM `FaissMIPSIndex` (every rank searches its shard for all questions and
 the results are merged on the device, instead of rank 0 searching and broadcasting, evaluate.py:100-127)."""
 import csv
-import json
 
 import torch
 

@@ -2,7 +2,6 @@
 megatron/training.py:165-230).  Same forward-step contract: forward_step(batch_or_iter, model) -> (loss, {'lm_loss', 'retriever_loss'})."""
 import time
 
-import numpy as np
 import torch
 
 from emdr2_amd import checkpointing
@@ -10,7 +9,7 @@ from emdr2_amd.global_vars import get_args
 from emdr2_amd.model.emdr2_model import emdr2_loss
 from emdr2_amd.tasks.openqa.e2eqa.eval_utils import exact_match_score, metric_max_over_ground_truths
 from emdr2_amd.tasks.openqa.e2eqa.train_data_utils import collate
-from emdr2_amd.training import AnnealingLR, FusedAdam, allreduce_gradients, get_params_for_weight_decay_optimization
+from emdr2_amd.training import AnnealingLR, allreduce_gradients
 
 
 def process_batch(batch):
