@@ -49,6 +49,9 @@ struct BwdParams {
 #ifndef DKV_OCC
 #define DKV_OCC 2
 #endif
+#ifndef KNW
+#define KNW 4                  // waves (32 keys each) per workgroup of the dK / dV kernel
+#endif
 template <bool DROP, bool CAUSAL>
 __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams p)
 {
@@ -209,7 +212,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
 
 // ========================================================== dk, dv ===================================================================
 template <bool DROP, bool CAUSAL>
-__global__ void __launch_bounds__(BNW * 64, DKV_OCC) attention_bwd_dkv_kernel(BwdParams p)
+__global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(BwdParams p)
 {
     // 2 stages x (Q tile 8 KiB + dO tile 8 KiB); per-query statistics of the block: pm, D, row hash, flags (64 each)
     __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
@@ -220,8 +223,8 @@ __global__ void __launch_bounds__(BNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     int kblk, b, n;
-    if (!attn_decode(blockIdx.x, (p.sk + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, kblk, b, n)) return;
-    const int k0 = kblk * (BNW * 32) + wave * 32;
+    if (!attn_decode(blockIdx.x, (p.sk + KNW * 32 - 1) / (KNW * 32), p.batch * p.heads, p.heads, kblk, b, n)) return;
+    const int k0 = kblk * (KNW * 32) + wave * 32;
     const int key = k0 + l31;
     const bool wave_live = k0 < p.sk;                                   // sk % 32 == 0: a wave's 32 keys are all valid or all out of range
     const int kc = wave_live ? key : p.sk - 1;
@@ -240,10 +243,10 @@ __global__ void __launch_bounds__(BNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
-        for (int i = 0; i < 8 / BNW; ++i) {
-            long long qr = blk * 64 + prow + 8 * BNW * i; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
-            __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
+        for (int i = 0; i < 8 / KNW; ++i) {
+            long long qr = blk * 64 + prow + 8 * KNW * i; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
+            __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + (wave + KNW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + KNW * i) * 1024), 16, 0, 0);
         }
     };
     // per-query statistics of a block, loaded by wave 0 one block ahead into registers and written to LDS a block later, so the
@@ -426,10 +429,10 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
     else if (causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_bwd_dq_kernel<false, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    const dim3 kv_grid(attn_grid((sk + BNW * 32 - 1) / (BNW * 32), batch * heads));
-    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, true>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, false>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else if (causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, false>), kv_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
+    const dim3 kv_grid(attn_grid((sk + KNW * 32 - 1) / (KNW * 32), batch * heads));
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, false>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, false>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }

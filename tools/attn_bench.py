@@ -4,6 +4,10 @@ import time
 
 import torch
 
+import os
+from emdr2_amd import _native
+if "--lib" in sys.argv:                                   # another build of the library (A/B experiments)
+    i = sys.argv.index("--lib"); _native.LIB_PATH = os.path.abspath(sys.argv[i + 1]); del sys.argv[i:i + 2]
 from emdr2_amd.model import kernels as K
 
 b = int(sys.argv[1]) if len(sys.argv) > 1 else 800
