@@ -216,6 +216,8 @@ def run(ctx, steps, warmup, world):
                    "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
         # dominant kernels of the step: the dense linears (NT GEMM forward / input gradients, TN GEMM weight gradients)
         "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_PEAK_TFLOPS, "traffic": None,
+                     "traffic_note": "an aggregate over ~1,040 launches of 40 shapes has no per-launch byte count; FETCH_SIZE / WRITE_SIZE per shape and kernel: "
+                                     "profiles/r02_gemm_summary.json (per_kernel[*].hbm_read_gb against algorithmic_hbm_gb)",
                      "kernel": "gemm_nt (gemm8_kernel / gemm_nt_kernel) + gemm_tn_kernel: executed flops / summed per-launch hipEvent time (rank 0)",
                      "per_step": {k: {"ms": ms[i] / steps, "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0), "launches": int(nl[i] // steps)}
                                   for i, k in enumerate(kinds)},
