@@ -174,7 +174,14 @@ def run(ctx, steps, warmup, world):
         loss = ctx.step()
     fence()
     keep = choose_keep_last(ctx, world)
-    if keep > 0:                                             # one more untimed step so the allocator has grown before the timed region
+    full_ms = None
+    if keep > 0:
+        t0 = time.perf_counter()                             # for the record: one step with the reference's full per-layer recompute
+        loss = ctx.step()
+        fence()
+        full_ms = (time.perf_counter() - t0) * 1e3
+        warmup += 1
+        # then one more untimed step so the allocator has grown before the timed region
         ctx.model.set_recompute_keep_last(keep)
         try:
             loss = ctx.step()
@@ -185,7 +192,7 @@ def run(ctx, steps, warmup, world):
             ctx.opt.zero_grad()
             torch.cuda.empty_cache()
         fence()
-    ctx.keep_last = keep
+    ctx.keep_last, ctx.full_recompute_ms = keep, (full_ms if keep > 0 else None)
     lib.emdr2_ops_set_timing(1)
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -210,6 +217,7 @@ def run(ctx, steps, warmup, world):
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (activations kept in HBM)" % ctx.keep_last if ctx.keep_last else ""),
+                   "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()),
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                    "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
