@@ -126,31 +126,45 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
         const int col = wc * 32 + colgrp * 16 + (t & 3) * 4;
         b_rd = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
     }
-    bf16x8 av[2][4], b0v[4], b1v[4];
+    // Fragment halves as raw 8-byte pairs.  The reads are inline asm on purpose: for the ds_read_tr builtin the compiler's wait-count pass
+    // assumes the read may alias every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of it -- in every phase, which collapsed the
+    // eight-half-tile DMA pipeline to one (the first versions of this kernel ran like that).  The matching lgkmcnt wait is T8_WAIT_* below.
+    uint2 al[2][4], ah[2][4], b0l[4], b0h[4], b1l[4], b1h[4];
     int rd_off = 0;                                           // ring offset of the current K-tile's A0; B0, B1, A1 follow (with wrap-around)
     auto ring = [](int off) { return off >= T8_RING ? off - T8_RING : off; };
-#define T8_FRAG(BASE, OFF)                                                                                                                \
-    __builtin_bit_cast(bf16x8, __builtin_shufflevector(__builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)((BASE) + (OFF))),              \
-                                                       __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s4_t *)((BASE) + (OFF) + 1024)), 0, 1, 2, 3, 4, 5, 6, 7))
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+#define T8_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define T8_READ_A(SLOT)                                                                                                                   \
     _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                                                                       \
-        const char *base_ = smem + (uint32_t)(ring(rd_off + (SLOT) * T8_SLOT) + (int)a_rd[f]);                                             \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) av[f][ks] = T8_FRAG(base_, ks * 4096);                                           \
+        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + a_rd[f];                                                \
+        T8_TR(al[f][0], base_, 0); T8_TR(ah[f][0], base_, 1024); T8_TR(al[f][1], base_, 4096); T8_TR(ah[f][1], base_, 5120);              \
+        T8_TR(al[f][2], base_, 8192); T8_TR(ah[f][2], base_, 9216); T8_TR(al[f][3], base_, 12288); T8_TR(ah[f][3], base_, 13312);         \
     }
-#define T8_READ_B(SLOT, DST)                                                                                                              \
+#define T8_READ_B(SLOT, L, H)                                                                                                             \
     {                                                                                                                                     \
-        const char *base_ = smem + (uint32_t)(ring(rd_off + (SLOT) * T8_SLOT) + (int)b_rd);                                                \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) DST[ks] = T8_FRAG(base_, ks * 4096);                                             \
+        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + b_rd;                                                   \
+        T8_TR(L[0], base_, 0); T8_TR(H[0], base_, 1024); T8_TR(L[1], base_, 4096); T8_TR(H[1], base_, 5120);                              \
+        T8_TR(L[2], base_, 8192); T8_TR(H[2], base_, 9216); T8_TR(L[3], base_, 12288); T8_TR(H[3], base_, 13312);                         \
     }
+#define T8_WAIT_A()                                                                                                                       \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                   \
+                 : "+v"(al[0][0]), "+v"(ah[0][0]), "+v"(al[0][1]), "+v"(ah[0][1]), "+v"(al[0][2]), "+v"(ah[0][2]), "+v"(al[0][3]), "+v"(ah[0][3]),   \
+                   "+v"(al[1][0]), "+v"(ah[1][0]), "+v"(al[1][1]), "+v"(ah[1][1]), "+v"(al[1][2]), "+v"(ah[1][2]), "+v"(al[1][3]), "+v"(ah[1][3])    \
+                 :: "memory")
+#define T8_WAIT_B(L, H)                                                                                                                   \
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L[0]), "+v"(H[0]), "+v"(L[1]), "+v"(H[1]), "+v"(L[2]), "+v"(H[2]), "+v"(L[3]), "+v"(H[3])::"memory")
+#define T8_FR(L, H) __builtin_bit_cast(bf16x8, make_uint4((L).x, (L).y, (H).x, (H).y))
     // rows of the MFMA result = i (A fragment first), columns = j: a lane holds one j and 16 i, so 32 lanes write 128 contiguous bytes of C
-#define T8_MFMA(MH, NH, BV)                                                                                                               \
+#define T8_MFMA(MH, NH, BL, BH)                                                                                                           \
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[f][ks], BV[ks], acc[2 * (MH) + f][NH], 0, 0, 0)
-#define T8_SYNC_COMPUTE(MFMAS)                                                                                                            \
+            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T8_FR(al[f][ks], ah[f][ks]), T8_FR(BL[ks], BH[ks]), acc[2 * (MH) + f][NH], 0, 0, 0)
+#define T8_SYNC_COMPUTE(WAIT, MFMAS)                                                                                                      \
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
     __builtin_amdgcn_s_barrier();                                                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                                                    \
+    WAIT;                                                                                                                                 \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
     __builtin_amdgcn_s_setprio(1);                                                                                                        \
     MFMAS;                                                                                                                                \
@@ -174,7 +188,7 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     if (want_colsum) {                                                                                                                    \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
             _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                            \
-                const uint4 w_ = __builtin_bit_cast(uint4, av[f][ks]);                                                                    \
+                const uint4 w_ = make_uint4(al[f][ks].x, al[f][ks].y, ah[f][ks].x, ah[f][ks].y);                                          \
                 float s_ = csum[2 * (MH) + f];                                                                                            \
                 s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.x), ones2, s_, false);                               \
                 s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.y), ones2, s_, false);                               \
@@ -191,25 +205,25 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     if (wr == 1) { T8_BARRIER(); }
 
     for (int kt = 0; kt < KT; ++kt) {
-        T8_READ_B(1, b0v); T8_READ_A(0);
+        T8_READ_B(1, b0l, b0h); T8_READ_A(0);
         __builtin_amdgcn_sched_barrier(0);
         T8_STAGE(0);
-        T8_SYNC_COMPUTE(T8_MFMA(0, 0, b0v));
+        T8_SYNC_COMPUTE(T8_WAIT_B(b0l, b0h); T8_WAIT_A(), T8_MFMA(0, 0, b0l, b0h));
         T8_COLSUM(0);
         T8_BARRIER();
-        T8_READ_B(2, b1v);
+        T8_READ_B(2, b1l, b1h);
         __builtin_amdgcn_sched_barrier(0);
         T8_STAGE(1);
-        T8_SYNC_COMPUTE(T8_MFMA(0, 1, b1v));
+        T8_SYNC_COMPUTE(T8_WAIT_B(b1l, b1h), T8_MFMA(0, 1, b1l, b1h));
         T8_BARRIER();
         T8_READ_A(3);
         __builtin_amdgcn_sched_barrier(0);
         T8_STAGE(2);
-        T8_SYNC_COMPUTE(T8_MFMA(1, 1, b1v));
+        T8_SYNC_COMPUTE(T8_WAIT_A(), T8_MFMA(1, 1, b1l, b1h));
         T8_COLSUM(1);
         T8_BARRIER();
         T8_STAGE(3);
-        T8_SYNC_COMPUTE(T8_MFMA(1, 0, b0v));
+        T8_SYNC_COMPUTE(, T8_MFMA(1, 0, b0l, b0h));
         rd_off = ring(rd_off + 4 * T8_SLOT);
         if (kt + 1 < KT) { T8_BARRIER(); }
     }
