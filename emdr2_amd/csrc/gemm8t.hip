@@ -182,19 +182,27 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
     float csum[4] = {0.f, 0.f, 0.f, 0.f};
-    const bool want_colsum = p.colsum && tj == 0 && wc == 0;                   // wave-uniform
+    // Bias gradient colsum[i] += sum_r A[r, i].  Every A fragment must be summed exactly once across the tiles_j workgroups that read the same
+    // A columns and the four waves (wc) that hold the same fragments: K-tile kt belongs to the tile with tj == kt % tiles_j, k-step ks to the
+    // wave with wc == ks.  (The first version gave all of it to the wc == 0 waves of the tj == 0 tiles: 32 v_dot2 per K-tile on one wave in
+    // eight, at ~24 cycles apiece beside MFMAs -- those workgroups ran 26 % longer and the launch waits for its slowest workgroup.)
+    const int tiles_j = p.tiles / p.tiles_i;
+    const bool want_colsum = p.colsum != nullptr;             // wave-uniform
+    int cs_phase = tj;                                        // counts down to this tile's K-tiles
     const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
 #define T8_COLSUM(MH)                                                                                                                     \
-    if (want_colsum) {                                                                                                                    \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                                            \
-                const uint4 w_ = make_uint4(al[f][ks].x, al[f][ks].y, ah[f][ks].x, ah[f][ks].y);                                          \
-                float s_ = csum[2 * (MH) + f];                                                                                            \
-                s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.x), ones2, s_, false);                               \
-                s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.y), ones2, s_, false);                               \
-                s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.z), ones2, s_, false);                               \
-                s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.w), ones2, s_, false);                               \
-                csum[2 * (MH) + f] = s_;                                                                                                  \
+    if (want_colsum && cs_phase == 0) {                                                                                                   \
+        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
+            if (ks == wc) {                                                                                                               \
+                _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                                                           \
+                    const uint4 w_ = make_uint4(al[f][ks].x, al[f][ks].y, ah[f][ks].x, ah[f][ks].y);                                      \
+                    float s_ = csum[2 * (MH) + f];                                                                                        \
+                    s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.x), ones2, s_, false);                           \
+                    s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.y), ones2, s_, false);                           \
+                    s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.z), ones2, s_, false);                           \
+                    s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.w), ones2, s_, false);                           \
+                    csum[2 * (MH) + f] = s_;                                                                                              \
+                }                                                                                                                         \
             }                                                                                                                             \
     }
 
@@ -221,6 +229,7 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
         T8_STAGE(2);
         T8_SYNC_COMPUTE(T8_WAIT_A(), T8_MFMA(1, 1, b1l, b1h));
         T8_COLSUM(1);
+        cs_phase = cs_phase == 0 ? tiles_j - 1 : cs_phase - 1;
         T8_BARRIER();
         T8_STAGE(3);
         T8_SYNC_COMPUTE(, T8_MFMA(1, 0, b0l, b0h));
