@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
         }
     };
-    uint32_t vtr[2][2];
+    uint32_t vtr[2][2], kra[4];
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
+    row_frag_addresses((uint32_t)(uintptr_t)smem, lane, kra);
     for (int blk = wave; blk < nblk; blk += NW) {
         const int key = blk * KB + lane;
         const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
@@ -134,7 +135,6 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
         if ((kmask == 0ull || (CAUSAL && key0 > q0 + QW - 1)) && !any_qpad && blk > 0 &&
             __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
             continue;
-        const char *sb = smem + stage * 16384;
         const uint32_t av0[2] = {vtr[0][0] + (uint32_t)(stage * 16384), vtr[0][1] + (uint32_t)(stage * 16384)};
         const uint32_t av1[2] = {vtr[1][0] + (uint32_t)(stage * 16384), vtr[1][1] + (uint32_t)(stage * 16384)};
 
@@ -191,12 +191,19 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                 continue;
             }
             // ---- S^T = K Q^T : 32 keys x 4 k-steps -------------------------------------------------------------------------------
-            const int krow = j * 32 + l31;
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C operand: no v_mov per register
-            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
+            // two fragments at a time: all four at once cost eight more live registers than the 168 of three waves per SIMD allow
+            const uint32_t so = (uint32_t)(stage * 16384);
+            bf16x8 kr[2];
+            floatx16 sacc;
 #pragma unroll
-            for (int t = 1; t < 4; ++t)
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
+            for (int tp = 0; tp < 2; ++tp) {
+                if (j == 0) { LDS_READ128(kr[0], kra[2 * tp] + so, 0); LDS_READ128(kr[1], kra[2 * tp + 1] + so, 0); }
+                else { LDS_READ128(kr[0], kra[2 * tp] + so, 4096); LDS_READ128(kr[1], kra[2 * tp + 1] + so, 4096); }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr[0]), "+v"(kr[1])::"memory");
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[0], qf[2 * tp], tp == 0 ? zero : sacc, 0, 0, 0);
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[1], qf[2 * tp + 1], sacc, 0, 0, 0);
+            }
             // ---- mask, online softmax (this lane: one query, 16 of the 32 keys; its half-wave partner holds the other 16) --------
             const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0);   // wave-uniform
             auto softmax_step = [&](auto masks) {

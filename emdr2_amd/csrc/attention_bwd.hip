@@ -114,8 +114,9 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
-    uint32_t ktr[2][2];
+    uint32_t ktr[2][2], kra[4];
     tr_addresses((uint32_t)(uintptr_t)smem, lane, ktr);
+    row_frag_addresses((uint32_t)(uintptr_t)smem, lane, kra);
 
     floatx16 dqacc[2];
 #pragma unroll
@@ -136,7 +137,6 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         const int key0 = blk * 64;
         // every (query of this wave, key of this block) pair masked -> dS == 0: nothing to add
         if (!wave_live || all_qpad || kmask == 0ull || (CAUSAL && key0 > q0 + 31)) continue;
-        const char *sb = smem + stage * 16384;
         const uint32_t a0[2] = {ktr[0][0] + (uint32_t)(stage * 16384), ktr[0][1] + (uint32_t)(stage * 16384)};
         const uint32_t a1[2] = {ktr[1][0] + (uint32_t)(stage * 16384), ktr[1][1] + (uint32_t)(stage * 16384)};
 #pragma unroll
@@ -145,13 +145,17 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
             const int kb0 = key0 + 32 * j;
             if (kb0 >= p.sk || km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int krow = j * 32 + l31;
-            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, hi), qf[0], zero, 0, 0, 0);
-            floatx16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, hi), dof[0], zero, 0, 0, 0);
+            // row fragments of the K and V tiles by inline asm (attention_common.h: a plain load would wait for the next block's DMA first)
+            const uint32_t so = (uint32_t)(stage * 16384);
+            floatx16 sacc, pacc;
 #pragma unroll
-            for (int t = 1; t < 4; ++t) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, krow, 2 * t + hi), qf[t], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, krow, 2 * t + hi), dof[t], pacc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                bf16x8 kr, vr;
+                if (j == 0) { LDS_READ128(kr, kra[t] + so, 0); LDS_READ128(vr, kra[t] + so, 8192); }
+                else { LDS_READ128(kr, kra[t] + so, 4096); LDS_READ128(vr, kra[t] + so, 8192 + 4096); }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(kr), "+v"(vr)::"memory");
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr, qf[t], t == 0 ? zero : sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vr, dof[t], t == 0 ? zero : pacc, 0, 0, 0);
             }
             // dS^T = P^T (dP^T_eff - D); masked -> 0
             const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0) || __builtin_amdgcn_ballot_w64(qpad) != 0ull;   // wave-uniform
@@ -267,7 +271,8 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
         st_pm[stage][lane] = nx_pm; st_d[stage][lane] = nx_d; st_rh[stage][lane] = nx_rh;
         if (lane == 0) st_qreal[stage] = nx_real;
     };
-    uint32_t qtr[2][2], otr[2][2];
+    uint32_t qtr[2][2], otr[2][2], qra[4];
+    row_frag_addresses((uint32_t)(uintptr_t)smem, lane, qra);
     tr_addresses((uint32_t)(uintptr_t)smem, lane, qtr);
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, otr);
 
@@ -296,20 +301,23 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
         // keys of this wave all ahead of every query of the block: P == 0 exactly and dS == 0
         if (!wave_live || (CAUSAL && k0 > qb0 + 63)) continue;
         const unsigned long long qreal = st_qreal[stage];
-        const char *sb = smem + stage * 16384;
 
         // the block's 64 queries in two halves of 32 (keeps the live accumulators at dK, dV + one S / dP pair)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             __builtin_amdgcn_sched_barrier(0);                             // keeps the two halves' fragment reads from being hoisted together
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            const int qrow = j * 32 + l31;
-            floatx16 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, qrow, hi), kf[0], zero, 0, 0, 0);
-            floatx16 pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, qrow, hi), vf[0], zero, 0, 0, 0);
+            // row fragments of the Q and dO tiles by inline asm (attention_common.h: a plain load would wait for the next block's DMA first)
+            const uint32_t so = (uint32_t)(stage * 16384);
+            floatx16 sacc, pacc;
 #pragma unroll
-            for (int t = 1; t < 4; ++t) {
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb, qrow, 2 * t + hi), kf[t], sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tile_row_frag(sb + 8192, qrow, 2 * t + hi), vf[t], pacc, 0, 0, 0);
+            for (int t = 0; t < 4; ++t) {
+                bf16x8 qr, orr;
+                if (j == 0) { LDS_READ128(qr, qra[t] + so, 0); LDS_READ128(orr, qra[t] + so, 8192); }
+                else { LDS_READ128(qr, qra[t] + so, 4096); LDS_READ128(orr, qra[t] + so, 8192 + 4096); }
+                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qr), "+v"(orr)::"memory");
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kf[t], t == 0 ? zero : sacc, 0, 0, 0);
+                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(orr, vf[t], t == 0 ? zero : pacc, 0, 0, 0);
             }
             // this lane: one key, queries ql = j*32 + 8g + 4hi + e.  sacc <- dS, pacc <- dropped P.  Masks are rare (padding, the causal
             // diagonal, the last query block): a wave-uniform test picks the mask-free form of the element loop otherwise

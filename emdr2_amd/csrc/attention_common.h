@@ -40,6 +40,28 @@ __device__ __forceinline__ bf16x8 tile_row_frag(const char *tile, int row, int g
     return *(const bf16x8 *)(tile + row * 128 + ((gran ^ tile_swz(row)) << 4));
 }
 
+// The same row fragments by inline asm, for the kernels that have an LDS-DMA in flight while they read (all of them: the next block is
+// staged while this one is consumed).  For a plain load from the staging buffer the compiler's wait-count pass assumes it may alias the DMA
+// destination and puts s_waitcnt vmcnt(0) in front of it: the prefetch of the next block was waited for BEFORE the current block was touched
+// and the double buffering hid nothing.  row_frag_addresses: the lane's byte address (row = lane & 31, stage 0) for k-step t = 0..3; the
+// second 32-row half of a tile is offset 4096, a stage 16384.
+__device__ __forceinline__ void row_frag_addresses(uint32_t tile_lds, int lane, uint32_t (&a)[4])
+{
+    const int row = lane & 31, hi = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) a[t] = tile_lds + row * 128 + (((2 * t + hi) ^ tile_swz(row)) << 4);
+}
+#define LDS_READ128(dst, addr, off) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
+#define ROW_FRAGS4(d, a, so, off)                                                                                   \
+    do {                                                                                                            \
+        LDS_READ128((d)[0], (a)[0] + (so), off); LDS_READ128((d)[1], (a)[1] + (so), off);                           \
+        LDS_READ128((d)[2], (a)[2] + (so), off); LDS_READ128((d)[3], (a)[3] + (so), off);                           \
+    } while (0)
+#define LDS_WAIT4(d) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"((d)[0]), "+v"((d)[1]), "+v"((d)[2]), "+v"((d)[3])::"memory")
+#define LDS_WAIT8(d, e)                                                                                             \
+    asm volatile("s_waitcnt lgkmcnt(0)"                                                                             \
+                 : "+v"((d)[0]), "+v"((d)[1]), "+v"((d)[2]), "+v"((d)[3]), "+v"((e)[0]), "+v"((e)[1]), "+v"((e)[2]), "+v"((e)[3])::"memory")
+
 // Transposed fragments: for the 16-row k-step starting at tile row `rb` (multiple of 16) the lane (col c = jsub*32 + lane&31, half hi) gets rows
 // rb + 4 hi + {0,1,2,3} and rb + 8 + 4 hi + {0,1,2,3} of column c -- the row subset a lane's accumulator registers 8(u&1)..8(u&1)+7 cover.
 // tr_base[jsub][which] holds the lane's byte address for rb = 0.
