@@ -77,6 +77,18 @@ SIGNATURES.update({
 })
 
 
+SIGNATURES.update({
+    "emdr2_seq_lengths": (_i32, [_vp, _i32, _i32, _vp, _vp, _vp]),
+    "emdr2_seq_pack_ids": (_i32, [_vp, _vp, _vp, _i32, _i32, _i64, _i64, _vp, _vp, _vp, _vp, _vp]),
+    "emdr2_gather_rows": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_scatter_rows": (_i32, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_embedding_packed_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _u32, _vp]),
+    "emdr2_embedding_packed_bwd": (_i32, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _f32, _u32, _vp]),
+    "emdr2_attention_varlen_fwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _i64, _i64,
+                                          _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _vp]),
+    "emdr2_attention_varlen_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
+                                          _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp]),
+})
 SIGNATURES["emdr2_gemm_nt_lse_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["emdr2_retriever_prior_fwd"] = (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])
 SIGNATURES["emdr2_retriever_prior_bwd"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])

@@ -34,6 +34,10 @@ struct AttnParams {
     int heads, sq, sk, causal, batch;
     float scale, drop_p;
     uint32_t seed;
+    // packed ("varlen") operands: sequence b owns rows [cu[b], cu[b+1]) of a [rows, heads, 64] tensor (no batch stride, no padding rows);
+    // NULL = the dense [batch, s] layout.  With cu_q the row statistics are laid out [heads, tq]; sq / sk are then the LONGEST sequence.
+    const int *cu_q, *cu_k;
+    long long tq;
 };
 
 // exchange between lane i and lane i + 32 (the two halves of a wave hold the two key subsets of one query): v_permlane32_swap with the value
@@ -70,30 +74,38 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const int l31 = lane & 31, hi = lane >> 5;
     int qblk, b, n;
     if (!attn_decode(blockIdx.x, (p.sq + QB - 1) / QB, p.batch * p.heads, p.heads, qblk, b, n)) return;
+    // this sequence's extent: dense = [b * s, b * s + s) with a batch stride; packed = rows [cu[b], cu[b+1])
+    int sq = p.sq, sk = p.sk;
+    long long qrow0 = (long long)b * p.sq, krow0 = (long long)b * p.sk;            // first row of the sequence in ids / o / (k)
+    long long q_off = (long long)b * p.q_sb, k_off = (long long)b * p.k_sb, v_off = (long long)b * p.v_sb;
+    long long stat0 = ((long long)b * p.heads + n) * p.sq;
+    if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; qrow0 = c0; q_off = (long long)c0 * p.q_ss; stat0 = (long long)n * p.tq + c0; }
+    if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; krow0 = c0; k_off = (long long)c0 * p.k_ss; v_off = (long long)c0 * p.v_ss; }
+    if (qblk * QB >= sq || sk < 1) return;                                        // (packed: a block past the end of a short sequence)
     const int q0 = qblk * QB + wave * QW;
     const int qi = q0 + l31;                       // this lane's query
-    const bool qvalid = qi < p.sq;
-    const int qc = qvalid ? qi : p.sq - 1;
+    const bool qvalid = qi < sq;
+    const int qc = qvalid ? qi : sq - 1;
 
     // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
-    const char *qrow = p.q + ((long long)b * p.q_sb + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
+    const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
     bf16x8 qf[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) qf[t] = *(const bf16x8 *)(qrow + (16 * t + 8 * hi) * 2);
-    const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
+    const bool qpad = !qvalid || p.ids_q[qrow0 + qc] == 0;
 
     // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves pieces w, w + NW, .. of each: 8 rows x 128 B,
     // lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row) (tile_swz has period 8 in the row)
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
-    const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
-    const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = (p.sk + KB - 1) / KB;
-    auto issue = [&](int blk, int stage) {                                     // sk % 32 == 0 (checked on the host)
+    const char *k_src = p.k + (k_off + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
+    const char *v_src = p.v + (v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
+    const int nblk = (sk + KB - 1) / KB;
+    auto issue = [&](int blk, int stage) {                                     // dense: sk % 32 == 0 (checked on the host); packed: any sk
         char *sb = smem + stage * 16384;
 #pragma unroll
         for (int i = 0; i < 8 / NW; ++i) {
             long long key = blk * KB + prow + 8 * NW * i;
-            if (key >= p.sk) key = p.sk - 1;                                       // the half block past sk (sk % 64 == 32): re-read, masked below
+            if (key >= sk) key = sk - 1;                                           // keys past sk: re-read the last row, masked below (kmask bit 0)
             __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + NW * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
         }
@@ -103,7 +115,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     row_frag_addresses((uint32_t)(uintptr_t)smem, lane, kra);
     for (int blk = wave; blk < nblk; blk += NW) {
         const int key = blk * KB + lane;
-        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < sk && p.ids_k[krow0 + (key < sk ? key : sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
 
@@ -120,7 +132,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     float mrun = -3.0e38f, lrun = 0.f;
     const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
-    const uint32_t rh = emdr2_row_hash(p.seed, ((unsigned long long)b * p.heads + n) * p.sq + (unsigned)qc);
+    const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)(stat0 + qc));
 
     issue(0, 0);
     for (int blk = 0; blk < nblk; ++blk) {
@@ -142,7 +154,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
         for (int j = 0; j < 2; ++j) {                                             // two 32-key online-softmax steps per staged block
             const uint32_t km = (uint32_t)(kmask >> (32 * j));
             const int kb0 = key0 + 32 * j;
-            if (kb0 >= p.sk) continue;                                            // sk % 64 == 32: the second half of the last block does not exist
+            if (kb0 >= sk) continue;                                              // the second half of the last block does not exist
             if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
                 __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
                 continue;
@@ -260,7 +272,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     // ---- normalise and store O[q, d]: lane q holds d = j*32 + (r&3) + 8(r>>2) + 4*half --------------------------------------
     if (qvalid) {
         const float inv = ik / lrun;                                 // survivors of the attention dropout are scaled here, once
-        uint16_t *orow = (uint16_t *)p.o + (((long long)b * p.sq + qi) * p.heads + n) * 64;
+        uint16_t *orow = (uint16_t *)p.o + ((qrow0 + qi) * p.heads + n) * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -271,7 +283,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                 *(uint2 *)(orow + d) = make_uint2(w0, w1);
             }
         if (hi == 0 && p.m) {
-            const long long si = ((long long)b * p.heads + n) * p.sq + qi;
+            const long long si = stat0 + qi;
             p.m[si] = mrun * 0.6931471805599453f; p.l[si] = lrun;        // back to natural-log units
         }
     }
@@ -279,24 +291,45 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
 
 } // namespace
 
-extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
-                                   int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream)
+static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
+                                int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, const int32_t *cu_q, const int32_t *cu_k,
+                                int64_t total_q, double pairs, void *stream)
 {
     if (!q || !k || !v || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (head_dim != 64 || sk < 32 || (sk & 31) || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
+    if (head_dim != 64 || sk < 1 || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
+    if (!cu_k && (sk < 32 || (sk & 31))) return -4;                                  // dense keys: whole 32-key steps (padded queries average over exactly sk keys)
+    if (cu_q && total_q < 1) return -1;
     if (((uintptr_t)q & 15) || ((uintptr_t)k & 15) || ((uintptr_t)v & 15) || ((uintptr_t)o & 7) || drop_p < 0.f || drop_p >= 1.f) return -1;
     AttnParams p;
     p.q = (const char *)q; p.k = (const char *)k; p.v = (const char *)v; p.o = (char *)o;
     p.ids_q = (const long long *)ids_q; p.ids_k = (const long long *)ids_k; p.m = m; p.l = l;
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
-    p.batch = batch;
+    p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
     dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads));
-    OpsTimer timer(OPS_ATTN_FWD, 4.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
+    OpsTimer timer(OPS_ATTN_FWD, 4.0 * heads * pairs * 64, (hipStream_t)stream);
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
     else if (causal) hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
+                                   int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream)
+{
+    return attention_fwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, ids_q, ids_k, batch, heads, sq, sk, head_dim, causal, scale, drop_p,
+                                seed, m, l, nullptr, nullptr, 0, (double)batch * sq * sk, stream);
+}
+
+extern "C" int emdr2_attention_varlen_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                          const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k,
+                                          const int32_t *cu_q, const int32_t *cu_k, int64_t total_q, int64_t pairs, int batch, int heads, int max_sq, int max_sk,
+                                          int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream)
+{
+    if (!cu_q && !cu_k) return -1;
+    return attention_fwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, ids_q, ids_k, batch, heads, max_sq, max_sk, head_dim, causal, scale,
+                                drop_p, seed, m, l, cu_q, cu_k, total_q, (double)pairs, stream);
 }

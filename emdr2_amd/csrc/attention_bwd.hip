@@ -40,7 +40,34 @@ struct BwdParams {
     int heads, sq, sk, causal, batch;
     float scale, drop_p;
     uint32_t seed;
+    // packed operands (attention.hip: AttnParams): sequence b owns rows [cu[b], cu[b+1]); statistics [heads, tq] when cu_q is given
+    const int *cu_q, *cu_k;
+    long long tq;
 };
+
+// the sequence's extent and operand offsets, dense or packed (see attention.hip)
+struct SeqExtent {
+    int sq, sk;
+    long long qrow0, krow0, q_off, k_off, v_off, dq_off, dkv_off, stat0;
+};
+__device__ __forceinline__ SeqExtent seq_extent(const BwdParams &p, int b, int n)
+{
+    SeqExtent e;
+    e.sq = p.sq; e.sk = p.sk;
+    e.qrow0 = (long long)b * p.sq; e.krow0 = (long long)b * p.sk;
+    e.q_off = (long long)b * p.q_sb; e.k_off = (long long)b * p.k_sb; e.v_off = (long long)b * p.v_sb;
+    e.dq_off = (long long)b * p.dq_sb; e.dkv_off = (long long)b * p.dkv_sb;
+    e.stat0 = ((long long)b * p.heads + n) * p.sq;
+    if (p.cu_q) {
+        const int c0 = p.cu_q[b];
+        e.sq = p.cu_q[b + 1] - c0; e.qrow0 = c0; e.q_off = (long long)c0 * p.q_ss; e.dq_off = (long long)c0 * p.dq_ss; e.stat0 = (long long)n * p.tq + c0;
+    }
+    if (p.cu_k) {
+        const int c0 = p.cu_k[b];
+        e.sk = p.cu_k[b + 1] - c0; e.krow0 = c0; e.k_off = (long long)c0 * p.k_ss; e.v_off = (long long)c0 * p.v_ss; e.dkv_off = (long long)c0 * p.dkv_ss;
+    }
+    return e;
+}
 
 // ============================================================ dq =====================================================================
 // Like the forward (attention.hip): VALU-bound, so workgroups are FOUR waves (128 queries) at <= 168 VGPRs -- three per CU, each on its own
@@ -62,17 +89,20 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const int l31 = lane & 31, hi = lane >> 5;
     int qblk, b, n;
     if (!attn_decode(blockIdx.x, (p.sq + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const SeqExtent ex = seq_extent(p, b, n);
+    const int sq = ex.sq, sk = ex.sk;
+    if (qblk * (BNW * 32) >= sq || sk < 1) return;
     const int q0 = qblk * (BNW * 32) + wave * 32;
     const int qi = q0 + l31;
-    const bool qvalid = qi < p.sq;
-    const int qc = qvalid ? qi : p.sq - 1;
-    const bool wave_live = q0 < p.sq;
+    const bool qvalid = qi < sq;
+    const int qc = qvalid ? qi : sq - 1;
+    const bool wave_live = q0 < sq;
 
     bf16x8 qf[4], dof[4];
-    load_row_frags(p.q + ((long long)b * p.q_sb + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2, hi, qf);
-    const long long orow = (((long long)b * p.sq + qc) * p.heads + n) * 64;
+    load_row_frags(p.q + (ex.q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2, hi, qf);
+    const long long orow = ((ex.qrow0 + qc) * p.heads + n) * 64;
     load_row_frags(p.dout + orow * 2, hi, dof);
-    const long long si = ((long long)b * p.heads + n) * p.sq + qc;
+    const long long si = ex.stat0 + qc;
     float Dq;
     {   // D = dO . O over this row (two half-rows, one per half-wave)
         bf16x8 of[4];
@@ -90,28 +120,28 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         }
         if (qvalid && hi == 0) p.dstat[si] = Dq;
     }
-    const bool qpad = !qvalid || p.ids_q[(long long)b * p.sq + qc] == 0;
+    const bool qpad = !qvalid || p.ids_q[ex.qrow0 + qc] == 0;
     const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;  // a wave of padded queries: every dS is 0
     const float sc = p.scale * L2E;
     const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
 
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
-    const char *k_src = p.k + ((long long)b * p.k_sb + (long long)n * p.k_sn) * 2 + pslot * 16;
-    const char *v_src = p.v + ((long long)b * p.v_sb + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = (p.sk + 63) / 64;
+    const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2 + pslot * 16;
+    const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
+    const int nblk = (sk + 63) / 64;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
         for (int i = 0; i < 8 / BNW; ++i) {
             long long key = blk * 64 + prow + 8 * BNW * i;
-            if (key >= p.sk) key = p.sk - 1;                                       // the half block past sk (sk % 64 == 32): re-read, masked below
+            if (key >= sk) key = sk - 1;                                           // keys past sk: re-read the last row, masked below
             __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
         }
     };
     for (int blk = wave; blk < nblk; blk += BNW) {
         const int key = blk * 64 + lane;
-        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < p.sk && p.ids_k[(long long)b * p.sk + (key < p.sk ? key : p.sk - 1)] != 0);
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(key < sk && p.ids_k[ex.krow0 + (key < sk ? key : sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
     }
     uint32_t ktr[2][2], kra[4];
@@ -143,7 +173,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         for (int j = 0; j < 2; ++j) {                                             // two 32-key steps per staged block
             const uint32_t km = (uint32_t)(kmask >> (32 * j));
             const int kb0 = key0 + 32 * j;
-            if (kb0 >= p.sk || km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
+            if (kb0 >= sk || km == 0u || (CAUSAL && kb0 > q0 + 31)) continue;                  // every pair of this step masked: dS == 0
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             // row fragments of the K and V tiles by inline asm (attention_common.h: a plain load would wait for the next block's DMA first)
             const uint32_t so = (uint32_t)(stage * 16384);
@@ -202,7 +232,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         }
     }
     if (qvalid) {
-        uint16_t *drow = (uint16_t *)p.dq + (long long)b * p.dq_sb + (long long)qi * p.dq_ss + n * 64;
+        uint16_t *drow = (uint16_t *)p.dq + ex.dq_off + (long long)qi * p.dq_ss + n * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -228,27 +258,31 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const int l31 = lane & 31, hi = lane >> 5;
     int kblk, b, n;
     if (!attn_decode(blockIdx.x, (p.sk + KNW * 32 - 1) / (KNW * 32), p.batch * p.heads, p.heads, kblk, b, n)) return;
+    const SeqExtent ex = seq_extent(p, b, n);
+    const int sq = ex.sq, sk = ex.sk;
+    if (kblk * (KNW * 32) >= sk || sq < 1) return;
     const int k0 = kblk * (KNW * 32) + wave * 32;
     const int key = k0 + l31;
-    const bool wave_live = k0 < p.sk;                                   // sk % 32 == 0: a wave's 32 keys are all valid or all out of range
-    const int kc = wave_live ? key : p.sk - 1;
+    const bool wave_live = k0 < sk;
+    const bool kvalid = key < sk;                                       // (dense: sk % 32 == 0, so a live wave's keys are all valid)
+    const int kc = kvalid ? key : sk - 1;
 
     bf16x8 kf[4], vf[4];
-    load_row_frags(p.k + ((long long)b * p.k_sb + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
-    load_row_frags(p.v + ((long long)b * p.v_sb + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
-    const bool kpad = !wave_live || p.ids_k[(long long)b * p.sk + kc] == 0;
+    load_row_frags(p.k + (ex.k_off + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
+    load_row_frags(p.v + (ex.v_off + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
+    const bool kpad = !kvalid || p.ids_k[ex.krow0 + kc] == 0;
     const float sc = p.scale * L2E;
 
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
-    const char *q_src = p.q + ((long long)b * p.q_sb + (long long)n * p.q_sn) * 2 + pslot * 16;
-    const char *o_src = p.dout + (((long long)b * p.sq) * p.heads + n) * 128 + pslot * 16;
-    const int nblk = (p.sq + 63) / 64;
-    const long long sbase = ((long long)b * p.heads + n) * p.sq;
+    const char *q_src = p.q + (ex.q_off + (long long)n * p.q_sn) * 2 + pslot * 16;
+    const char *o_src = p.dout + (ex.qrow0 * p.heads + n) * 128 + pslot * 16;
+    const int nblk = (sq + 63) / 64;
+    const long long sbase = ex.stat0;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
         for (int i = 0; i < 8 / KNW; ++i) {
-            long long qr = blk * 64 + prow + 8 * KNW * i; if (qr >= p.sq) qr = p.sq - 1;     // overhang queries re-read the last row; masked out below
+            long long qr = blk * 64 + prow + 8 * KNW * i; if (qr >= sq) qr = sq - 1;         // overhang queries re-read the last row; masked out below
             __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + (wave + KNW * i) * 1024), 16, 0, 0);
             __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + KNW * i) * 1024), 16, 0, 0);
         }
@@ -260,12 +294,12 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     unsigned long long nx_real = 0;
     auto load_stats = [&](int blk) {
         const int qq = blk * 64 + lane;
-        const bool valid = qq < p.sq;
-        const long long si = sbase + (valid ? qq : p.sq - 1);
+        const bool valid = qq < sq;
+        const long long si = sbase + (valid ? qq : sq - 1);
         nx_pm = p.m[si] * L2E + __log2f(p.l[si]);
         nx_d = p.dstat[si];
         nx_rh = emdr2_row_hash(p.seed, (unsigned long long)si);
-        nx_real = __builtin_amdgcn_ballot_w64(valid && p.ids_q[(long long)b * p.sq + (valid ? qq : 0)] != 0);
+        nx_real = __builtin_amdgcn_ballot_w64(valid && p.ids_q[ex.qrow0 + (valid ? qq : 0)] != 0);
     };
     auto store_stats = [&](int stage) {
         st_pm[stage][lane] = nx_pm; st_d[stage][lane] = nx_d; st_rh[stage][lane] = nx_rh;
@@ -323,7 +357,7 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
             // diagonal, the last query block): a wave-uniform test picks the mask-free form of the element loop otherwise
             const uint32_t qr32 = (uint32_t)(qreal >> (32 * j));
             const int qh0 = qb0 + 32 * j;
-            const bool need_mask = __builtin_amdgcn_ballot_w64(kpad) != 0ull || qr32 != 0xffffffffu || (CAUSAL && k0 + 31 > qh0) || qh0 + 31 >= p.sq;
+            const bool need_mask = __builtin_amdgcn_ballot_w64(kpad) != 0ull || qr32 != 0xffffffffu || (CAUSAL && k0 + 31 > qh0) || qh0 + 31 >= sq;
             auto elements = [&](auto masks) {
                 constexpr bool MASKS = decltype(masks)::value;
 #pragma unroll
@@ -342,7 +376,7 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
                         if (MASKS) {
                             masked = kpad || !((qr32 >> ql) & 1u) || (CAUSAL && key > qg);
                             pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
-                            pr = qg < p.sq ? pr : 0.f;                        // rows beyond sq do not exist
+                            pr = qg < sq ? pr : 0.f;                          // rows beyond sq do not exist
                         } else {
                             pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pmv[e]));
                         }
@@ -393,9 +427,9 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
             }
         }
     }
-    if (wave_live) {
-        uint16_t *krow = (uint16_t *)p.dk + (long long)b * p.dkv_sb + (long long)key * p.dkv_ss + n * 64;
-        uint16_t *vrow = (uint16_t *)p.dv + (long long)b * p.dkv_sb + (long long)key * p.dkv_ss + n * 64;
+    if (kvalid) {
+        uint16_t *krow = (uint16_t *)p.dk + ex.dkv_off + (long long)key * p.dkv_ss + n * 64;
+        uint16_t *vrow = (uint16_t *)p.dv + ex.dkv_off + (long long)key * p.dkv_ss + n * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -410,13 +444,16 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
 
 } // namespace
 
-extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
-                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
-                                   int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
-                                   int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
+static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                                int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
+                                int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, const int32_t *cu_q, const int32_t *cu_k,
+                                int64_t total_q, double pairs, void *stream)
 {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (head_dim != 64 || sk < 32 || (sk & 31) || sk > 65536) return -4;
+    if (head_dim != 64 || sk < 1 || sk > 65536) return -4;
+    if (!cu_k && (sk < 32 || (sk & 31))) return -4;
+    if (cu_q && total_q < 1) return -1;
     const int64_t strides[13] = {q_sb, q_ss, q_sn, k_sb, k_ss, k_sn, v_sb, v_ss, v_sn, dq_sb, dq_ss, dkv_sb, dkv_ss};
     for (int i = 0; i < 13; ++i)
         if (strides[i] & 7) return -4;
@@ -430,8 +467,8 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dkv_sb = dkv_sb; p.dkv_ss = dkv_ss;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
-    p.batch = batch;
-    OpsTimer timer(OPS_ATTN_BWD, 10.0 * batch * (double)heads * sq * sk * 64, (hipStream_t)stream);
+    p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
+    OpsTimer timer(OPS_ATTN_BWD, 10.0 * heads * pairs * 64, (hipStream_t)stream);
     const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads));
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
@@ -443,4 +480,24 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
     else if (causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, false>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
+}
+
+extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                   const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                                   int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
+                                   int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
+{
+    return attention_bwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, dout, dq, dq_sb, dq_ss, dk, dv, dkv_sb, dkv_ss, ids_q, ids_k, m, l,
+                                dstat, batch, heads, sq, sk, head_dim, causal, scale, drop_p, seed, nullptr, nullptr, 0, (double)batch * sq * sk, stream);
+}
+
+extern "C" int emdr2_attention_varlen_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                          const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                                          int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k,
+                                          const int32_t *cu_q, const int32_t *cu_k, int64_t total_q, int64_t pairs, const float *m, const float *l, float *dstat,
+                                          int batch, int heads, int max_sq, int max_sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream)
+{
+    if (!cu_q && !cu_k) return -1;
+    return attention_bwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, dout, dq, dq_sb, dq_ss, dk, dv, dkv_sb, dkv_ss, ids_q, ids_k, m, l,
+                                dstat, batch, heads, max_sq, max_sk, head_dim, causal, scale, drop_p, seed, cu_q, cu_k, total_q, (double)pairs, stream);
 }

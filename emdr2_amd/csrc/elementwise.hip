@@ -501,10 +501,21 @@ __global__ void __launch_bounds__(256) gelu_bwd_kernel(const uint16_t *pre, cons
 
 // ---- embedding (language_model.py:169-181): out = W[ids] + P[pos] (+ T[types]) ------------------------------------------------
 __global__ void __launch_bounds__(256) embedding_fwd_kernel(const long long *ids, const long long *types, const uint16_t *W, const uint16_t *P,
-                                                            const uint16_t *T, uint16_t *out, long long tokens, int S, int H, float drop_p, uint32_t seed)
+                                                            const uint16_t *T, uint16_t *out, long long tokens, int S, int H, float drop_p, uint32_t seed,
+                                                            const int *rowmap)
 {
+    // rowmap (packed layout, csrc/seqpack.hip): row t holds the token of dense row rowmap[t] = sequence * S + position; -1 = a tail row (zeros)
     const long long t = blockIdx.x;
-    const long long id = ids[t], pos = t % S;
+    long long pos = t % S;
+    if (rowmap) {
+        const int src = rowmap[t];
+        if (src < 0) {
+            for (int i = threadIdx.x; i < H; i += 256) out[t * H + i] = 0;
+            return;
+        }
+        pos = src % S;
+    }
+    const long long id = ids[t];
     const long long ty = types ? types[t] : 0;
     for (int i = threadIdx.x; i < H; i += 256) {
         float v = bf2f(W[id * H + i]) + bf2f(P[pos * H + i]);
@@ -539,16 +550,22 @@ __global__ void __launch_bounds__(256) embedding_bwd_kernel(const long long *ids
 // serialises thousands of adds on a few addresses.  One thread owns (position, column), walks the batch, and writes the position sum
 // with a plain add; the type sums (<= 4 types) are kept in registers and cost one atomic per (position, column) instead of one per token.
 __global__ void __launch_bounds__(256) embedding_bwd_pos_kernel(const long long *types, const uint16_t *dout, float *dP, float *dT, long long tokens,
-                                                                int S, int H, int n_types, float drop_p, uint32_t seed)
+                                                                int S, int H, int n_types, float drop_p, uint32_t seed, const int *cu, int nseq)
 {
+    // cu (packed layout): sequence b owns rows [cu[b], cu[b+1]); its position `pos` exists iff pos < its length
     const int pos = blockIdx.x, i = blockIdx.y * 256 + threadIdx.x;
     if (i >= H) return;
-    const long long nb = tokens / S;
+    const long long nb = cu ? nseq : tokens / S;
     const uint32_t thr = emdr2_drop_thr(drop_p);
     const float ik = drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f;
     float ap = 0.f, at[4] = {0.f, 0.f, 0.f, 0.f};
     for (long long b = 0; b < nb; ++b) {
-        const long long t = b * S + pos;
+        long long t = b * S + pos;
+        if (cu) {
+            const int c0 = cu[b];
+            if (pos >= cu[b + 1] - c0) continue;
+            t = c0 + pos;
+        }
         float g = bf2f(dout[t * H + i]);
         if (drop_p > 0.f) g = emdr2_keep(emdr2_row_hash(seed, (unsigned long long)t), (uint32_t)i, thr) ? g * ik : 0.f;
         ap += g;
@@ -842,7 +859,16 @@ extern "C" int emdr2_embedding_fwd(const int64_t *ids, const int64_t *types, con
 {
     if (!ids || !W || !P || !out || tokens < 1 || S < 1 || H < 1 || (types && !T) || drop_p < 0.f || drop_p >= 1.f) return -1;
     hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
-                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)tokens, S, H, drop_p, seed);
+                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)tokens, S, H, drop_p, seed, (const int *)nullptr);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_embedding_packed_fwd(const int64_t *ids, const int64_t *types, const int32_t *rowmap, const void *W, const void *P, const void *T, void *out,
+                                          int64_t rows, int S, int H, float drop_p, uint32_t seed, void *stream)
+{
+    if (!ids || !rowmap || !W || !P || !out || rows < 1 || S < 1 || H < 1 || (types && !T) || drop_p < 0.f || drop_p >= 1.f) return -1;
+    hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
+                       (const uint16_t *)W, (const uint16_t *)P, (const uint16_t *)T, (uint16_t *)out, (long long)rows, S, H, drop_p, seed, (const int *)rowmap);
     return LAUNCH_OK();
 }
 
@@ -854,7 +880,20 @@ extern "C" int emdr2_embedding_bwd(const int64_t *ids, const int64_t *types, con
     hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)tokens), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
                        (const uint16_t *)dout, dW, dP, dT, (long long)tokens, S, H, drop_p, seed);
     hipLaunchKernelGGL(embedding_bwd_pos_kernel, dim3((unsigned)S, (unsigned)((H + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       (const long long *)types, (const uint16_t *)dout, dP, dT, (long long)tokens, S, H, n_types, drop_p, seed);
+                       (const long long *)types, (const uint16_t *)dout, dP, dT, (long long)tokens, S, H, n_types, drop_p, seed, (const int *)nullptr, 0);
+    return LAUNCH_OK();
+}
+
+extern "C" int emdr2_embedding_packed_bwd(const int64_t *ids, const int64_t *types, const int32_t *cu, int nseq, const void *dout, float *dW, float *dP, float *dT,
+                                          int64_t rows, int S, int H, int n_types, float drop_p, uint32_t seed, void *stream)
+{
+    if (!ids || !cu || nseq < 1 || !dout || !dW || !dP || rows < 1 || S < 1 || H < 1 || (types && !dT) || drop_p < 0.f || drop_p >= 1.f) return -1;
+    if (types && (n_types < 1 || n_types > 4)) return -4;
+    // word rows: the same atomic scatter (a tail row carries a zero gradient and is skipped like any zero row)
+    hipLaunchKernelGGL(embedding_bwd_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const long long *)ids, (const long long *)types,
+                       (const uint16_t *)dout, dW, dP, dT, (long long)rows, S, H, drop_p, seed);
+    hipLaunchKernelGGL(embedding_bwd_pos_kernel, dim3((unsigned)S, (unsigned)((H + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const long long *)types, (const uint16_t *)dout, dP, dT, (long long)rows, S, H, n_types, drop_p, seed, (const int *)cu, nseq);
     return LAUNCH_OK();
 }
 

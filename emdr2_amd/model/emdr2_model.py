@@ -211,8 +211,15 @@ class EMDR2Model(torch.nn.Module):
         topk_log_probs = K.retriever_prior(query_logits, ctx_logits, 1.0 / math.sqrt(H) if self.retriever_score_scaling else 1.0)
 
         S = qext.shape[1]
-        enc = self.language_model.encode(qext).reshape(B, Kk * S, H)                          # K passages concatenated (FiD), :148-164
-        lm_logits = self.language_model.decode(dec_ids, enc, qext.reshape(B, Kk * S))           # :166-183
+        packed = self.language_model.language_model.packs()
+        if packed:
+            # the reader encoder over real tokens only; a question's K passages are consecutive sequences of the packed buffer, so the FiD
+            # concatenation (:159-161) is the same rows seen as B groups of K sequences -- no pad rows between the passages
+            enc, seqs = self.language_model.encode_packed(qext)
+            lm_logits = self.language_model.decode(dec_ids, enc, seqs.grouped(Kk))
+        else:
+            enc = self.language_model.encode(qext).reshape(B, Kk * S, H)                      # K passages concatenated (FiD), :148-164
+            lm_logits = self.language_model.decode(dec_ids, enc, qext.reshape(B, Kk * S))       # :166-183
 
         one = None
         if self.training and self.update_retriever:
@@ -220,16 +227,18 @@ class EMDR2Model(torch.nn.Module):
                 dec_rep = torch.repeat_interleave(dec_ids, Kk, dim=0)
                 K.DROPOUT.pass_id = 1                                                         # a second, independent draw of every dropout site
                 try:
-                    enc1 = self.language_model.encode(qone)
+                    enc1, ids1 = self.language_model.encode_packed(qone) if packed else (self.language_model.encode(qone), qone)
                     if self.fuse_lm_head_loss:
-                        hid = self.language_model.decode_hidden(dec_rep, enc1, qone)
+                        hid = self.language_model.decode_hidden(dec_rep, enc1, ids1)
                         one = OneContextLogits(hid.reshape(B, Kk, dec_ids.shape[1], H), self.language_model.language_model.embedding.word_embeddings.weight,
                                                self.language_model.lm_head.bias)
                     else:
-                        one = self.language_model.decode(dec_rep, enc1, qone).reshape(B, Kk, dec_ids.shape[1], -1)
+                        one = self.language_model.decode(dec_rep, enc1, ids1).reshape(B, Kk, dec_ids.shape[1], -1)
                 finally:
                     K.DROPOUT.pass_id = 0
         if not self.training:
+            if packed:                                                                       # the reference's shapes for the eval-mode return (:211-214)
+                enc = K.unpack_rows(enc, seqs).reshape(B, Kk * S, H)
             return lm_logits, topk_log_probs, enc, qext.reshape(B, Kk * S)
         return lm_logits, topk_log_probs, one
 

@@ -179,6 +179,117 @@ def _accum_grad(p, g_f32):
         p.grad += g_f32        # rare (a parameter used twice in one backward): tied embedding / LM head
 
 
+# ---- packed ("varlen") sequence layout ---------------------------------------------------------------------------------------
+class _Packing(object):
+    """Switch for the packed layout of the encoder stacks (csrc/seqpack.hip): ON = the context tower, the reader encoder and the
+    one-context pass run only over real tokens (every consumed value is unchanged, see PackedSeqs); OFF = the reference's [batch, S] grids."""
+
+    def __init__(self):
+        self.enabled = True
+
+
+PACKING = _Packing()
+
+
+class PackedSeqs(object):
+    """Layout of n sequences of <= S tokens stored back to back without their trailing [PAD] rows (include/emdr2_ops.h, "packed
+    sequences"): sequence i owns rows [cu[i], cu[i+1]) of every [rows, ...] tensor of the stack; `rows` = the real token count `total`
+    rounded up to ROW_MULTIPLE (tail rows hold zeros / token id 0, so the persistent GEMMs see whole 256-row tiles and weight gradients
+    are unaffected).  Building it costs one host sync (the row count sizes every activation of the stack).
+    Why this is exact: a padded key contributes exp(-10000 - max) == 0 to every real query of the reference's masked softmax
+    (transformer.py:283-381 with bert/t5_attention_mask_func), and padded queries are consumed by nothing (token 0 of the towers,
+    dualencoder_model.py:166-181; the FiD decoder masks padded encoder positions, emdr2_model.py:166-183) and receive zero gradient."""
+    ROW_MULTIPLE = 256
+
+    def __init__(self, ids, types=None):
+        if ids.dim() != 2 or ids.dtype != torch.int64 or not ids.is_cuda:
+            raise TypeError("token ids must be a CUDA int64 [n, S] tensor")
+        ids = ids.contiguous()
+        types = types.contiguous() if types is not None else None
+        n, S = ids.shape
+        dev = ids.device
+        lib = _lib()
+        self.n, self.S, self.max_len, self.group = n, S, S, 1
+        self.cu = torch.empty(n + 1, dtype=torch.int32, device=dev)
+        totals = torch.empty(2, dtype=torch.int64, device=dev)
+        _native.check(lib.emdr2_seq_lengths(ids.data_ptr(), n, S, self.cu.data_ptr(), totals.data_ptr(), _sp()), "seq_lengths")
+        self.total, self.pairs = (int(v) for v in totals.tolist())                  # the layout's one host sync
+        m = self.ROW_MULTIPLE
+        self.rows = (self.total + m - 1) // m * m
+        self.rowmap = torch.empty(self.rows, dtype=torch.int32, device=dev)         # packed row -> dense row (i * S + pos), -1 in the tail
+        self.inverse = torch.empty(n * S, dtype=torch.int32, device=dev)            # dense row -> packed row, -1 at dropped pad rows
+        self.ids = torch.empty(self.rows, dtype=torch.int64, device=dev)
+        self.types = torch.empty(self.rows, dtype=torch.int64, device=dev) if types is not None else None
+        _native.check(lib.emdr2_seq_pack_ids(ids.data_ptr(), _ptr(types), self.cu.data_ptr(), n, S, self.total, self.rows, self.rowmap.data_ptr(),
+                                             self.inverse.data_ptr(), self.ids.data_ptr(), _ptr(self.types), _sp()), "seq_pack_ids")
+
+    def grouped(self, k):
+        """The same rows seen as n / k sequences, each the concatenation of k consecutive ones: the FiD decoder's keys (the K passages of a
+        question concatenated, emdr2_model.py:159-161) -- contiguous in the packed buffer, no pad rows in between."""
+        if k == 1:
+            return self
+        if self.group != 1 or self.n % k:
+            raise ValueError("grouping needs an ungrouped layout of a multiple of k sequences")
+        g = object.__new__(PackedSeqs)
+        g.__dict__.update(self.__dict__)
+        g.n, g.max_len, g.group = self.n // k, self.S * k, k
+        g.cu = self.cu[::k].contiguous()
+        g.pairs = None
+        return g
+
+    def zero_tail(self, t):
+        if self.rows > self.total:
+            t[self.total:].zero_()
+        return t
+
+
+class GatherRowsFn(torch.autograd.Function):
+    """out[r] = x[fwd_map[r]] (zeros where the map is negative) over bf16 rows; backward = the gather through `bwd_map` when the caller has
+    the inverse map (pack <-> unpack), else a scatter into zeros (token-0 rows of a packed tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, fwd_map, rows_out, bwd_map):
+        _check_bf16(x)
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H)
+        out = torch.empty((rows_out, H), dtype=BF16, device=x.device)
+        _native.check(_lib().emdr2_gather_rows(x2.data_ptr(), fwd_map.data_ptr(), out.data_ptr(), rows_out, H, _sp()), "gather_rows")
+        ctx.fwd_map, ctx.bwd_map, ctx.in_shape = fwd_map, bwd_map, x.shape
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        H = dy.shape[-1]
+        rows_in = 1
+        for d in ctx.in_shape[:-1]:
+            rows_in *= d
+        if ctx.bwd_map is not None:
+            dx = torch.empty((rows_in, H), dtype=BF16, device=dy.device)
+            _native.check(_lib().emdr2_gather_rows(dy.data_ptr(), ctx.bwd_map.data_ptr(), dx.data_ptr(), rows_in, H, _sp()), "gather_rows")
+        else:
+            dx = torch.zeros((rows_in, H), dtype=BF16, device=dy.device)
+            _native.check(_lib().emdr2_scatter_rows(dy.data_ptr(), ctx.fwd_map.data_ptr(), dx.data_ptr(), dy.shape[0], H, _sp()), "scatter_rows")
+        return dx.reshape(ctx.in_shape), None, None, None
+
+
+def unpack_rows(x, seqs):
+    """packed [rows, H] -> dense [n, S, H] with zeros at the dropped pad positions (the reference's shape, for consumers that want it)."""
+    if seqs.group != 1:
+        raise ValueError("unpack through the ungrouped layout")
+    return GatherRowsFn.apply(x, seqs.inverse, seqs.n * seqs.S, seqs.rowmap).reshape(seqs.n, seqs.S, x.shape[-1])
+
+
+def pack_rows(x, seqs):
+    """dense [n, S, H] -> packed [rows, H]."""
+    return GatherRowsFn.apply(x, seqs.rowmap, seqs.rows, seqs.inverse)
+
+
+def first_rows(x, seqs):
+    """[n, H]: the row of token 0 of every sequence of a packed tensor (the towers' output, dualencoder_model.py:166-181)."""
+    return GatherRowsFn.apply(x, seqs.cu, seqs.n, None)
+
+
 # ---- autograd functions ----------------------------------------------------------------------------------------------------
 class LinearFn(torch.autograd.Function):
     """y = x W^T + b, optional exact-erf GELU, optional residual add (the reference's F.linear + bias(+gelu) / bias-dropout-add at
@@ -373,42 +484,71 @@ class _AttentionStash(object):
 ATTN_STASH = _AttentionStash()
 
 
+def _attn_side(x, info):
+    """Launch description of one attention operand: x [b, s, np, hn] over dense token ids [b, s], or x [rows, np, hn] over a PackedSeqs.
+    -> (ids, cu, batch stride, sequence stride, head stride, batch, longest sequence)."""
+    if isinstance(info, PackedSeqs):
+        if x.dim() != 3 or x.shape[0] != info.rows:
+            raise ValueError("a packed attention operand must be [rows, heads, head_dim]")
+        return info.ids, info.cu, 0, x.stride(0), x.stride(1), info.n, info.max_len
+    if info.dtype != torch.int64 or not info.is_contiguous() or not info.is_cuda:
+        raise TypeError("token ids must be contiguous CUDA int64 tensors (the kernels derive the masks from them)")
+    if x.dim() != 4:
+        raise ValueError("a dense attention operand must be [batch, s, heads, head_dim]")
+    return info, None, x.stride(0), x.stride(1), x.stride(2), x.shape[0], x.shape[1]
+
+
 class AttentionCoreFn(torch.autograd.Function):
     """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).
     Inputs are the projection outputs themselves: self-attention passes `qsrc` = the packed [b, s, 3, np, hn] QKV tensor (kvsrc None),
     cross-attention `qsrc` = [b, sq, np, hn] and `kvsrc` = the packed [b, sk, 2, np, hn] KV tensor.  The kernels read q, k, v as strided
     slices and the backward writes dq, dk, dv straight into ONE packed gradient (no select_backward zero-fill + add chains).
-    Masks come from token ids (pad id 0) + optional history mask.  hn == 64 and sk % 32 == 0 run the fused kernels (attention.hip,
-    attention_bwd.hip); other shapes run QK^T GEMM + softmax kernel + PV GEMM.  Only the row statistics (max, sum-exp) and the output are
-    kept; the backward rebuilds the probabilities from them."""
+    `ids_q` / `ids_k` are dense token ids [b, s] (masks: pad id 0 + optional history mask) or a PackedSeqs, in which case that side's
+    tensors are [rows, ...] without a batch dimension (sequence b = rows cu[b] .. cu[b+1]).  hn == 64 runs the fused kernels
+    (attention.hip, attention_bwd.hip; dense keys need sk % 32 == 0); other dense shapes run QK^T GEMM + softmax kernel + PV GEMM.
+    Only the row statistics (max, sum-exp) and the output are kept; the backward rebuilds the probabilities from them."""
 
     @staticmethod
     def forward(ctx, qsrc, kvsrc, ids_q, ids_k, causal, drop_p=0.0, seed=0, site=0):
         _check_bf16(qsrc, kvsrc)
-        for ids in (ids_q, ids_k):
-            if ids.dtype != torch.int64 or not ids.is_contiguous() or not ids.is_cuda:
-                raise TypeError("token ids must be contiguous CUDA int64 tensors (the kernels derive the masks from them)")
         if kvsrc is None:
-            q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
+            q, k, v = qsrc.select(-3, 0), qsrc.select(-3, 1), qsrc.select(-3, 2)
         else:
-            q, k, v = qsrc, kvsrc[:, :, 0], kvsrc[:, :, 1]
-        b, sq, heads, hn = q.shape
-        sk = k.shape[1]
+            q, k, v = qsrc, kvsrc.select(-3, 0), kvsrc.select(-3, 1)
+        pq, pk = isinstance(ids_q, PackedSeqs), isinstance(ids_k, PackedSeqs)
+        iq, cq, q_sb, q_ss, q_sn, b, sq = _attn_side(q, ids_q)
+        ik, ck, k_sb, k_ss, k_sn, bk, sk = _attn_side(k, ids_k)
+        _, _, v_sb, v_ss, v_sn, _, _ = _attn_side(v, ids_k)
+        if b != bk:
+            raise ValueError("query and key batches differ")
+        heads, hn = q.shape[-2:]
         dev = q.device
         scale = 1.0 / math.sqrt(hn)
+        ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
+        ctx.ids_q, ctx.ids_k = ids_q, ids_k
         stash_key = (ATTN_STASH.key, site) if (ATTN_STASH.enabled and ATTN_STASH.mode and site) else None
         stashed = ATTN_STASH.store.pop(stash_key, None) if (stash_key and ATTN_STASH.mode == 'consume') else None
         if stashed is not None:                                                           # the layer's re-run: reuse the first run's output
             ctxo, m, l = stashed
-            ctx.save_for_backward(qsrc, kvsrc, m, l, ids_q, ids_k, ctxo)
-            ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
+            ctx.save_for_backward(qsrc, kvsrc, m, l, ctxo)
             return ctxo
-        m = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
+        m = torch.empty((heads, ids_q.rows) if pq else (b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
-        ctxo = torch.empty((b, sq, heads, hn), dtype=BF16, device=dev)
-        if hn == 64 and sk % 32 == 0 and sk <= 65536:
-            _native.check(_lib().emdr2_attention_fwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
-                                                     k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq,
+        ctxo = torch.empty(tuple(q.shape[:-2]) + (heads, hn), dtype=BF16, device=dev)
+        fused = hn == 64 and sk <= 65536 and (pk or sk % 32 == 0)
+        if (pq or pk) and not fused:
+            raise ValueError("packed attention operands need head dim 64 (the fused kernels)")
+        if pq or pk:
+            pairs = ids_q.pairs if (pq and ids_k is ids_q) else (sq * ids_k.total if not pq else 0)
+            _native.check(_lib().emdr2_attention_varlen_fwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,
+                                                            ctxo.data_ptr(), iq.data_ptr(), ik.data_ptr(), _ptr(cq), _ptr(ck), ids_q.rows if pq else 0,
+                                                            int(pairs or 0), b, heads, sq, sk, hn, int(causal), scale, float(drop_p), int(seed),
+                                                            m.data_ptr(), l.data_ptr(), _sp()), "attention_varlen_fwd")
+            if pq:
+                ids_q.zero_tail(ctxo)
+        elif fused:
+            _native.check(_lib().emdr2_attention_fwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss,
+                                                     k_sn, v.data_ptr(), v_sb, v_ss, v_sn, ctxo.data_ptr(), iq.data_ptr(), ik.data_ptr(), b, heads, sq,
                                                      sk, hn, int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), _sp()),
                           "attention_fwd")
         else:
@@ -416,42 +556,60 @@ class AttentionCoreFn(torch.autograd.Function):
             S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
             gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2),
                     k.stride(2), sq * sk, alpha=scale)
-            _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), ids_q.data_ptr(), ids_k.data_ptr(), b, heads, sq, sk, int(causal),
+            _native.check(_lib().emdr2_softmax_mask_fwd(S.data_ptr(), iq.data_ptr(), ik.data_ptr(), b, heads, sq, sk, int(causal),
                                                         m.data_ptr(), l.data_ptr(), float(drop_p), int(seed), _sp()), "softmax_fwd")
             gemm_nt(S, sk, vT, sk, ctxo, heads * hn, sq, hn, sk, b, heads * sq * sk, heads * hn * sk, sq * heads * hn, heads, sq * sk, hn * sk, hn)
-        ctx.save_for_backward(qsrc, kvsrc, m, l, ids_q, ids_k, ctxo)
-        ctx.causal, ctx.drop_p, ctx.seed = causal, float(drop_p), int(seed)
+        ctx.save_for_backward(qsrc, kvsrc, m, l, ctxo)
         if stash_key and ATTN_STASH.mode == 'store':
             ATTN_STASH.store[stash_key] = (ctxo, m, l)
         return ctxo
 
     @staticmethod
     def backward(ctx, dctx):
-        qsrc, kvsrc, m, l, ids_q, ids_k, ctxo = ctx.saved_tensors
+        qsrc, kvsrc, m, l, ctxo = ctx.saved_tensors
+        ids_q, ids_k = ctx.ids_q, ctx.ids_k
         if kvsrc is None:
-            q, k, v = qsrc[:, :, 0], qsrc[:, :, 1], qsrc[:, :, 2]
+            q, k, v = qsrc.select(-3, 0), qsrc.select(-3, 1), qsrc.select(-3, 2)
             dqsrc, dkvsrc = torch.empty_like(qsrc), None
-            dq, dk, dv = dqsrc[:, :, 0], dqsrc[:, :, 1], dqsrc[:, :, 2]
+            dq, dk, dv = dqsrc.select(-3, 0), dqsrc.select(-3, 1), dqsrc.select(-3, 2)
         else:
-            q, k, v = qsrc, kvsrc[:, :, 0], kvsrc[:, :, 1]
+            q, k, v = qsrc, kvsrc.select(-3, 0), kvsrc.select(-3, 1)
             dqsrc, dkvsrc = torch.empty_like(qsrc), torch.empty_like(kvsrc)
-            dq, dk, dv = dqsrc, dkvsrc[:, :, 0], dkvsrc[:, :, 1]
-        b, sq, heads, hn = q.shape
-        sk = k.shape[1]
+            dq, dk, dv = dqsrc, dkvsrc.select(-3, 0), dkvsrc.select(-3, 1)
+        pq, pk = isinstance(ids_q, PackedSeqs), isinstance(ids_k, PackedSeqs)
+        iq, cq, q_sb, q_ss, q_sn, b, sq = _attn_side(q, ids_q)
+        ik, ck, k_sb, k_ss, k_sn, _, sk = _attn_side(k, ids_k)
+        _, _, v_sb, v_ss, v_sn, _, _ = _attn_side(v, ids_k)
+        _, _, dq_sb, dq_ss, _, _, _ = _attn_side(dq, ids_q)
+        _, _, dkv_sb, dkv_ss, _, _, _ = _attn_side(dk, ids_k)
+        heads, hn = q.shape[-2:]
         dev = q.device
         causal = int(ctx.causal)
         scale = 1.0 / math.sqrt(hn)
         dctx = dctx.contiguous()
         H = heads * hn
         lib = _lib()
-        D = torch.empty((b, heads, sq), dtype=torch.float32, device=dev)
+        D = torch.empty_like(m)
+        if pq or pk:
+            pairs = ids_q.pairs if (pq and ids_k is ids_q) else (sq * ids_k.total if not pq else 0)
+            _native.check(lib.emdr2_attention_varlen_bwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,
+                                                         ctxo.data_ptr(), dctx.data_ptr(), dq.data_ptr(), dq_sb, dq_ss, dk.data_ptr(), dv.data_ptr(), dkv_sb,
+                                                         dkv_ss, iq.data_ptr(), ik.data_ptr(), _ptr(cq), _ptr(ck), ids_q.rows if pq else 0, int(pairs or 0),
+                                                         m.data_ptr(), l.data_ptr(), D.data_ptr(), b, heads, sq, sk, hn, causal, scale, ctx.drop_p,
+                                                         ctx.seed, _sp()), "attention_varlen_bwd")
+            if pq:                                                                        # tail rows feed the weight-gradient GEMMs: zeros
+                ids_q.zero_tail(dqsrc)
+            if pk and dkvsrc is not None:
+                ids_k.zero_tail(dkvsrc)
+            return dqsrc, dkvsrc, None, None, None, None, None, None
         if hn == 64 and sk % 32 == 0 and sk <= 65536:                                     # fused: no [sq, sk] matrix, no operand transposes
             _native.check(lib.emdr2_attention_bwd(q.data_ptr(), q.stride(0), q.stride(1), q.stride(2), k.data_ptr(), k.stride(0), k.stride(1),
                                                   k.stride(2), v.data_ptr(), v.stride(0), v.stride(1), v.stride(2), ctxo.data_ptr(), dctx.data_ptr(),
                                                   dq.data_ptr(), dq.stride(0), dq.stride(1), dk.data_ptr(), dv.data_ptr(), dk.stride(0),
-                                                  dk.stride(1), ids_q.data_ptr(), ids_k.data_ptr(), m.data_ptr(), l.data_ptr(), D.data_ptr(), b,
+                                                  dk.stride(1), iq.data_ptr(), ik.data_ptr(), m.data_ptr(), l.data_ptr(), D.data_ptr(), b,
                                                   heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, _sp()), "attention_bwd")
             return dqsrc, dkvsrc, None, None, None, None, None, None
+        ids_q, ids_k = iq, ik
         # main orientation: S = scale Q K^T (recomputed), dP = dctx V^T, dS = P (dP_eff - D) with P rebuilt from (m, l)
         S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
         gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2), k.stride(2),
@@ -488,37 +646,53 @@ def attention_core(qsrc, kvsrc, ids_q, ids_k, causal=False, drop_p=0.0, seed=0, 
 
 class EmbeddingFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, ids, types, W, P, T, drop_p=0.0, seed=0):
-        b, s = ids.shape
+    def forward(ctx, ids, types, W, P, T, drop_p=0.0, seed=0, seqs=None):
         H = W.shape[1]
-        out = torch.empty((b, s, H), dtype=BF16, device=ids.device)
-        ids = ids.contiguous()
-        types = types.contiguous() if types is not None else None
-        _native.check(_lib().emdr2_embedding_fwd(ids.data_ptr(), _ptr(types), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
-                                                 w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), b * s, s, H, float(drop_p),
-                                                 int(seed), _sp()), "embedding_fwd")
-        ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T, ctx.drop_p, ctx.seed = ids, types, W, P, T, drop_p, seed
+        lib = _lib()
+        if seqs is not None:                                     # packed rows: ids / types come from the layout, positions from its row map
+            if (types is not None) != (seqs.types is not None):
+                raise ValueError("the packed layout was built without (with) the token types this embedding call passes (omits)")
+            ids, types, S = seqs.ids, seqs.types, seqs.S
+            out = torch.empty((seqs.rows, H), dtype=BF16, device=ids.device)
+            _native.check(lib.emdr2_embedding_packed_fwd(ids.data_ptr(), _ptr(types), seqs.rowmap.data_ptr(), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
+                                                         w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), seqs.rows, S, H,
+                                                         float(drop_p), int(seed), _sp()), "embedding_packed_fwd")
+        else:
+            b, s = ids.shape
+            out = torch.empty((b, s, H), dtype=BF16, device=ids.device)
+            ids = ids.contiguous()
+            types = types.contiguous() if types is not None else None
+            _native.check(lib.emdr2_embedding_fwd(ids.data_ptr(), _ptr(types), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
+                                                  w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), b * s, s, H, float(drop_p),
+                                                  int(seed), _sp()), "embedding_fwd")
+        ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T, ctx.drop_p, ctx.seed, ctx.seqs = ids, types, W, P, T, drop_p, seed, seqs
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        ids, types, W, P, T = ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T
-        b, s = ids.shape
+        ids, types, W, P, T, seqs = ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T, ctx.seqs
         H = W.shape[1]
         dout = dout.contiguous()
         dW, dP = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(P, dtype=torch.float32)
         dT = torch.zeros_like(T, dtype=torch.float32) if types is not None else None
-        _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
-                                                 T.shape[0] if dT is not None else 0, float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
+        if seqs is not None:
+            _native.check(_lib().emdr2_embedding_packed_bwd(ids.data_ptr(), _ptr(types), seqs.cu.data_ptr(), seqs.n, dout.data_ptr(), dW.data_ptr(),
+                                                            dP.data_ptr(), _ptr(dT), seqs.rows, seqs.S, H, T.shape[0] if dT is not None else 0,
+                                                            float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_packed_bwd")
+        else:
+            b, s = ids.shape
+            _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
+                                                     T.shape[0] if dT is not None else 0, float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
         _accum_grad(W, dW)
         _accum_grad(P, dP)
         if dT is not None:
             _accum_grad(T, dT)
-        return None, None, None, None, None, None, None
+        return None, None, None, None, None, None, None, None
 
 
-def embedding(ids, types, W, P, T, drop_p=0.0, seed=0):
-    return EmbeddingFn.apply(ids, types, W, P, T, drop_p, seed)
+def embedding(ids, types, W, P, T, drop_p=0.0, seed=0, seqs=None):
+    """ids [b, s] (+ types) -> [b, s, H]; or `seqs` = a PackedSeqs -> [rows, H] (ids / types are taken from the layout)."""
+    return EmbeddingFn.apply(ids, types, W, P, T, drop_p, seed, seqs)
 
 
 class LseGatherFn(torch.autograd.Function):

@@ -12,6 +12,10 @@ ids: pad id 0, plus the history mask for decoder self-attention) - `forward` the
 tensor model parallelism is not built (asserted 1 in the reference, dualencoder_model.py:15).  Dropout (embedding, attention probabilities,
 bias-dropout-add; active only in `.train()` mode) is counter-based inside the kernels (csrc/rng.h, kernels.DROPOUT): masks are regenerated
 in the backward / activation recompute, never stored.
+
+Packed layout (kernels.PACKING, csrc/seqpack.hip): the encoder stacks run over [rows, h] = only the real tokens of their sequences,
+stored back to back (`kernels.PackedSeqs`); `ids` arguments of the layers are then a PackedSeqs instead of a [b, s] id tensor.  The dense
+entry points (`encode`, `forward`) keep the reference's shapes: they unpack (zeros at pad rows) on the way out.
 """
 import math
 
@@ -97,23 +101,24 @@ class ParallelAttention(torch.nn.Module):
         self.kv_cache = None            # (encoder_output, kv): set by `cross_kv_cache` during greedy decoding
 
     def forward(self, x, ids_q, ids_k, causal, residual, encoder_output=None):
-        b, sq, h = x.shape
+        """x [b, sq, h] over dense ids, or [rows, h] over a PackedSeqs (likewise encoder_output / ids_k for cross-attention)."""
+        lead = tuple(x.shape[:-1])
         pa = self.attention_dropout if self.training else 0.0
         ph = self.hidden_dropout if self.training else 0.0
         seed = K.DROPOUT.seed(self._site_attn) if pa else 0
         if self.attention_type == "self":
-            mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(b, sq, 3, self.heads, self.hn)
-            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(b, sq, h)
+            mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(lead + (3, self.heads, self.hn))
+            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(x.shape)
         else:
-            sk = encoder_output.shape[1]
             if self.kv_cache is not None and self.kv_cache[0] is encoder_output:
                 kv = self.kv_cache[1]                                                     # K/V of the 25,600 encoder tokens, projected once
             else:
-                kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(b, sk, 2, self.heads, self.hn)
+                kv = K.linear(encoder_output, self.key_value.weight, self.key_value.bias, row_perm=self._perm).view(
+                    tuple(encoder_output.shape[:-1]) + (2, self.heads, self.hn))
                 if self.kv_cache is not None:
                     self.kv_cache = (encoder_output, kv)
-            q = K.linear(x, self.query.weight, self.query.bias).view(b, sq, self.heads, self.hn)
-            ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(b, sq, h)
+            q = K.linear(x, self.query.weight, self.query.bias).view(lead + (self.heads, self.hn))
+            ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(x.shape)
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
 
@@ -218,11 +223,13 @@ class Embedding(torch.nn.Module):
         self.tokentype_embeddings = _Table(num_tokentypes, cfg.hidden_size, cfg.init_method_std) if num_tokentypes > 0 else None
         self.embedding_dropout, self._site = cfg.hidden_dropout, K.DROPOUT.new_site()          # language_model.py:289: hidden_dropout
 
-    def forward(self, ids, tokentype_ids=None):
-        T = self.tokentype_embeddings.weight if tokentype_ids is not None else None
+    def forward(self, ids, tokentype_ids=None, seqs=None):
+        """[b, s, h] from ids (+ token types) [b, s]; or, with `seqs` (a PackedSeqs built from them), the packed [rows, h]."""
+        with_types = (seqs.types if seqs is not None else tokentype_ids) is not None
+        T = self.tokentype_embeddings.weight if with_types else None
         p = self.embedding_dropout if self.training else 0.0
-        return K.embedding(ids, tokentype_ids, self.word_embeddings.weight, self.position_embeddings.weight, T, drop_p=p,
-                           seed=K.DROPOUT.seed(self._site) if p else 0)
+        return K.embedding(ids, tokentype_ids if with_types else None, self.word_embeddings.weight, self.position_embeddings.weight, T, drop_p=p,
+                           seed=K.DROPOUT.seed(self._site) if p else 0, seqs=seqs)
 
 
 class TransformerLanguageModel(torch.nn.Module):
@@ -234,10 +241,24 @@ class TransformerLanguageModel(torch.nn.Module):
         if add_decoder:
             self.decoder = ParallelTransformer(cfg, "decoder", checkpoint_activations)
 
+    def packs(self):
+        """Whether this stack runs its encoder over packed rows: the switch is on and the fused attention kernels take the head size."""
+        return K.PACKING.enabled and self.encoder.layers[0].self_attention.hn == 64
+
+    def encode_packed(self, enc_ids, tokentype_ids=None):
+        """(hidden [rows, h], PackedSeqs): the encoder over the real tokens only."""
+        seqs = K.PackedSeqs(enc_ids, tokentype_ids)
+        return self.encoder(self.embedding(None, None, seqs=seqs), seqs), seqs
+
     def encode(self, enc_ids, tokentype_ids=None):
+        """[b, s, h] like the reference (language_model.py:319-342); with packing on, rows of dropped pad positions are zeros."""
+        if self.packs():
+            x, seqs = self.encode_packed(enc_ids, tokentype_ids)
+            return K.unpack_rows(x, seqs)
         return self.encoder(self.embedding(enc_ids, tokentype_ids), enc_ids)
 
     def decode(self, dec_ids, encoder_output, enc_ids):
+        """encoder_output [b, sk, h] with enc_ids [b, sk]; or the packed [rows, h] with a PackedSeqs of b (groups of) sequences."""
         return self.decoder(self.embedding(dec_ids), dec_ids, causal=True, encoder_output=encoder_output, enc_ids=enc_ids)
 
     # ---- incremental decoding (search_strategy.py:185-240 re-decodes the whole prefix for every token; SURVEY 8f-4) --------------------
@@ -288,6 +309,9 @@ class PretrainedBertModel(torch.nn.Module):
         self.language_model = TransformerLanguageModel(cfg, vocab_size, num_tokentypes, False, checkpoint_activations)
 
     def forward(self, input_ids, tokentype_ids=None):
+        if self.language_model.packs():
+            x, seqs = self.language_model.encode_packed(input_ids, tokentype_ids)
+            return K.first_rows(x, seqs)
         return self.language_model.encode(input_ids, tokentype_ids)[:, 0, :]
 
 
@@ -322,6 +346,10 @@ class T5Model(torch.nn.Module):
     def encode(self, encoder_input_ids):
         return self.language_model.encode(encoder_input_ids)
 
+    def encode_packed(self, encoder_input_ids):
+        """(hidden [rows, h], PackedSeqs) -- hand both to `decode` / `decode_hidden` (group the layout for FiD: `seqs.grouped(K)`)."""
+        return self.language_model.encode_packed(encoder_input_ids)
+
     def decode_hidden(self, decoder_input_ids, enc_hidden_states, enc_ids):
         """Decoder output before the LM head (for consumers that fuse the head with what follows it)."""
         return self.language_model.decode(decoder_input_ids, enc_hidden_states, enc_ids)
@@ -336,5 +364,8 @@ class T5Model(torch.nn.Module):
         return self.lm_head(dec, self.language_model.embedding.word_embeddings.weight)
 
     def forward(self, encoder_input_ids, decoder_input_ids):
+        if self.language_model.packs():
+            enc, seqs = self.encode_packed(encoder_input_ids)
+            return self.decode(decoder_input_ids, enc, seqs), K.unpack_rows(enc, seqs)
         enc = self.encode(encoder_input_ids)
         return self.decode(decoder_input_ids, enc, encoder_input_ids), enc

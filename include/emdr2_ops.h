@@ -91,6 +91,46 @@ int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
                         const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch, int heads, int sq,
                         int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream);
 
+/* ---- packed ("varlen") sequences: the encoder stacks without their [PAD] rows (csrc/seqpack.hip) -------------------------------------
+ * The reference runs [batch, S] token grids through every layer (transformer.py:283-381, emdr2_model.py:148-210); a padded key adds
+ * exp(-10000 - max) == 0 to every real query and a padded query's row is never consumed, so dropping those rows changes no consumed value.
+ * Layout: sequence i keeps its first len[i] tokens, len[i] = 1 + index of its last non-pad (id != 0) token (S for an all-pad row), and
+ * owns rows [cu[i], cu[i+1]) of a [rows, ...] tensor; cu = exclusive prefix sum of len (int32 [n+1]).
+ *
+ * emdr2_seq_lengths: cu from ids [n, S]; totals[0] = cu[n], totals[1] = sum len^2 (int64 [2], device).  n <= 16000.
+ * emdr2_seq_pack_ids: rowmap[t] (int32 [rows_padded]) = dense row i*S+pos of packed row t (-1 for t >= total: tail rows up to a GEMM-friendly
+ *   multiple), inverse[i*S+pos] (int32 [n*S]) = packed row or -1, ids_packed / types_packed (int64 [rows_padded], 0 in the tail).
+ * emdr2_gather_rows: out[r, :] = map[r] >= 0 ? in[map[r], :] : 0 (bf16 rows of H, H % 8 == 0) -- dense -> packed with rowmap, packed -> dense
+ *   (zeros at pad rows) with inverse, token-0 rows of a packed tensor with cu.  emdr2_scatter_rows: out[map[r], :] = in[r, :] (map[r] >= 0). */
+int emdr2_seq_lengths(const int64_t *ids, int n, int S, int32_t *cu, int64_t *totals, void *stream);
+int emdr2_seq_pack_ids(const int64_t *ids, const int64_t *types, const int32_t *cu, int n, int S, int64_t total, int64_t rows_padded,
+                       int32_t *rowmap, int32_t *inverse, int64_t *ids_packed, int64_t *types_packed, void *stream);
+int emdr2_gather_rows(const void *in, const int32_t *map, void *out, int64_t rows_out, int H, void *stream);
+int emdr2_scatter_rows(const void *in, const int32_t *map, void *out, int64_t rows_in, int H, void *stream);
+
+/* Embedding.forward / backward over packed rows (language_model.py:169-181): position = rowmap[t] % S; tail rows (rowmap < 0) are zeros.
+ * bwd: the position sums walk the sequences through cu (position p exists in sequence i iff p < len[i]). */
+int emdr2_embedding_packed_fwd(const int64_t *ids_packed, const int64_t *types_packed, const int32_t *rowmap, const void *W, const void *P, const void *T,
+                               void *out, int64_t rows, int S, int H, float drop_p, uint32_t seed, void *stream);
+int emdr2_embedding_packed_bwd(const int64_t *ids_packed, const int64_t *types_packed, const int32_t *cu, int nseq, const void *dout, float *dW, float *dP,
+                               float *dT, int64_t rows, int S, int H, int n_types, float drop_p, uint32_t seed, void *stream);
+
+/* The fused attention kernels over packed operands (same kernels as emdr2_attention_fwd / _bwd): cu_q and / or cu_k (int32 [batch+1], either
+ * may be NULL = that side is dense [batch, s] with its batch stride) give sequence b's rows [cu[b], cu[b+1]) of q / o / dq (k, v / dk, dv);
+ * ids_q / ids_k are indexed the same way (packed ids for a packed side).  max_sq / max_sk: the longest sequence (grid size; dense side: s);
+ * a packed key side takes ANY lengths >= 1 (keys past the end are masked).  With cu_q the row statistics m, l, dstat are [heads, total_q].
+ * pairs = sum_b sq_b * sk_b (flop accounting of the timing hooks only).  Replaces transformer.py:283-381 for the packed stacks and the
+ * FiD cross-attention of emdr2_model.py:166-183 over the packed encoder output (cu_k = every K-th entry of the encoder's cu). */
+int emdr2_attention_varlen_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                               const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k,
+                               const int32_t *cu_q, const int32_t *cu_k, int64_t total_q, int64_t pairs, int batch, int heads, int max_sq, int max_sk,
+                               int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, void *stream);
+int emdr2_attention_varlen_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                               const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                               int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k,
+                               const int32_t *cu_q, const int32_t *cu_k, int64_t total_q, int64_t pairs, const float *m, const float *l, float *dstat,
+                               int batch, int heads, int max_sq, int max_sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, void *stream);
+
 /* dpre = dact * gelu'(pre), exact-erf GELU (transformer.py:80,103-104; the tanh fusion of fused_bias_gelu.py is off in all scripts) */
 int emdr2_gelu_bwd(const void *pre, const void *dact, void *dpre, int64_t n, void *stream);
 

@@ -1,0 +1,293 @@
+"""GPU: the packed ("varlen") sequence layout (csrc/seqpack.hip, the cu_q / cu_k forms of the attention kernels, kernels.PackedSeqs)
+against the dense [batch, S] path it replaces (reference: transformer.py:283-381 over padded grids, emdr2_model.py:148-210).
+
+The claim under test: dropping a sequence's trailing [PAD] rows changes no CONSUMED value -- real positions, logits, losses and every
+parameter gradient agree with the dense path (and therefore with the oracle, which the dense path is tested against elsewhere)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import transformer_oracle as to
+
+pytestmark = pytest.mark.gpu
+CFG = dict(layers=2, hidden=128, heads=2, ffn=256, max_pos=128)
+
+
+def _cfg(**kw):
+    from emdr2_amd.model.transformer import Config
+    return Config(num_layers=CFG["layers"], hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], ffn_hidden_size=CFG["ffn"],
+                  max_position_embeddings=CFG["max_pos"], init_method_std=0.05, **kw)
+
+
+def _ragged_ids(rng, n, S, vocab, lo=1):
+    x = rng.integers(5, vocab, size=(n, S))
+    lens = rng.integers(lo, S + 1, size=n)
+    for r, ln in zip(x, lens):
+        r[ln:] = 0
+    return x.astype(np.int64), lens
+
+
+def _rel(a, b):
+    a, b = a.detach().float(), b.detach().float()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-6))
+
+
+# ---- the layout itself -------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,S", [(1, 8), (7, 64), (300, 100), (3200, 256), (5000, 33)])
+def test_layout_matches_numpy(n, S):
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(n * 1000 + S)
+    ids, lens = _ragged_ids(rng, n, S, 1000)
+    ids[0, :] = 0; lens[0] = S                               # an all-pad row keeps every position (the reference's uniform attention)
+    if n > 2 and S >= 8:
+        ids[2, 1] = 0                                        # an interior zero stays inside its sequence
+        ids[2, 5] = 7; lens[2] = max(lens[2], 6)
+    types = rng.integers(0, 2, size=(n, S)).astype(np.int64)
+    seqs = K.PackedSeqs(torch.from_numpy(ids).cuda(), torch.from_numpy(types).cuda())
+    cu = np.concatenate([[0], np.cumsum(lens)])
+    assert seqs.total == int(cu[-1]) and seqs.pairs == int((lens.astype(np.int64) ** 2).sum())
+    assert seqs.rows % K.PackedSeqs.ROW_MULTIPLE == 0 and 0 <= seqs.rows - seqs.total < K.PackedSeqs.ROW_MULTIPLE
+    assert np.array_equal(seqs.cu.cpu().numpy(), cu)
+    rowmap = np.full(seqs.rows, -1, dtype=np.int64)
+    inverse = np.full(n * S, -1, dtype=np.int64)
+    for i in range(n):
+        rowmap[cu[i]:cu[i + 1]] = i * S + np.arange(lens[i])
+        inverse[i * S:i * S + lens[i]] = cu[i] + np.arange(lens[i])
+    assert np.array_equal(seqs.rowmap.cpu().numpy(), rowmap)
+    assert np.array_equal(seqs.inverse.cpu().numpy(), inverse)
+    flat_ids, flat_types = ids.reshape(-1), types.reshape(-1)
+    want_ids = np.where(rowmap >= 0, flat_ids[np.maximum(rowmap, 0)], 0)
+    assert np.array_equal(seqs.ids.cpu().numpy(), want_ids)
+    assert np.array_equal(seqs.types.cpu().numpy(), np.where(rowmap >= 0, flat_types[np.maximum(rowmap, 0)], 0))
+    g = seqs.grouped(1)
+    assert g is seqs
+    if n % 5 == 0:
+        g5 = seqs.grouped(5)
+        assert g5.n == n // 5 and g5.max_len == 5 * S and np.array_equal(g5.cu.cpu().numpy(), cu[::5])
+
+
+def test_pack_unpack_first_rows_and_their_gradients():
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(3)
+    n, S, H = 37, 48, 128
+    ids, lens = _ragged_ids(rng, n, S, 500)
+    seqs = K.PackedSeqs(torch.from_numpy(ids).cuda())
+    real = torch.from_numpy(ids != 0).cuda()
+    x = torch.randn((n, S, H), device="cuda").bfloat16().requires_grad_(True)
+    xp = K.pack_rows(x, seqs)
+    assert xp.shape == (seqs.rows, H) and float(xp[seqs.total:].abs().max() if seqs.rows > seqs.total else 0) == 0.0
+    back = K.unpack_rows(xp, seqs)
+    assert torch.equal(back[real], x.detach()[real]) and float(back[~real].abs().max()) == 0.0
+    first = K.first_rows(xp, seqs)
+    assert torch.equal(first, x.detach()[:, 0])
+    w1, w2 = torch.randn_like(back, dtype=torch.float32), torch.randn_like(first, dtype=torch.float32)
+    ((back.float() * w1).sum() + (first.float() * w2).sum()).backward()
+    want = w1.bfloat16().float() * real[..., None]
+    want[:, 0] += w2.bfloat16().float()
+    assert torch.allclose(x.grad.float(), want, atol=4e-2, rtol=2e-2)           # (two bf16 roundings of the two contributions)
+    assert float(x.grad[~real].abs().max()) == 0.0
+
+
+def test_packed_embedding_equals_dense_at_real_positions():
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(4)
+    n, S, H, V = 21, 64, 128, 300
+    ids, _ = _ragged_ids(rng, n, S, V)
+    types = rng.integers(0, 2, size=(n, S)).astype(np.int64)
+    ids_t, types_t = torch.from_numpy(ids).cuda(), torch.from_numpy(types).cuda()
+    real = ids_t != 0
+    g = torch.Generator(device="cuda").manual_seed(1)
+    mk = lambda *s: torch.nn.Parameter(torch.randn(s, generator=g, device="cuda"))
+    W, P, T = mk(V, H), mk(S, H), mk(2, H)
+    dense = K.embedding(ids_t, types_t, W, P, T)
+    wgt = torch.randn(dense.shape, generator=g, device="cuda") * real[..., None]
+    (dense.float() * wgt).sum().backward()
+    gd = [p.grad.clone() for p in (W, P, T)]
+    for p in (W, P, T):
+        p.grad = None
+    seqs = K.PackedSeqs(ids_t, types_t)
+    packed = K.embedding(None, None, W, P, T, seqs=seqs)
+    assert torch.equal(K.unpack_rows(packed, seqs)[real], dense[real])
+    (K.unpack_rows(packed, seqs).float() * wgt).sum().backward()
+    for p, ref in zip((W, P, T), gd):
+        assert torch.allclose(p.grad, ref, rtol=1e-4, atol=1e-3)
+
+
+# ---- attention over packed operands -------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,S,heads,causal", [(5, 64, 2, False), (9, 256, 3, False), (4, 512, 2, False), (6, 96, 2, True), (3, 40, 1, False)])
+def test_packed_self_attention_equals_dense(n, S, heads, causal):
+    """Same kernels, cu_q = cu_k: outputs and q/k/v gradients at the real positions agree with the dense launch (which is tested against
+    fp32 torch in test_ops_gpu.py) -- lengths are arbitrary (not multiples of 32), one sequence has a single token."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(n * S)
+    ids, lens = _ragged_ids(rng, n, S, 500)
+    ids[1, 1:] = 0; lens[1] = 1
+    ids_t = torch.from_numpy(ids).cuda()
+    real = ids_t != 0
+    g = torch.Generator(device="cuda").manual_seed(S)
+    qkv = torch.randn((n, S, 3, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    out_d = K.attention_core(qkv, None, ids_t, ids_t, causal)
+    w = torch.randn(out_d.shape, generator=g, device="cuda") * real[..., None, None]
+    (out_d.float() * w).sum().backward()
+    grad_d = qkv.grad.clone(); qkv.grad = None
+    seqs = K.PackedSeqs(ids_t)
+    qkv_p = K.pack_rows(qkv.reshape(n, S, -1), seqs).reshape(seqs.rows, 3, heads, 64)
+    out_p = K.attention_core(qkv_p, None, seqs, seqs, causal)
+    assert out_p.shape == (seqs.rows, heads, 64)
+    if seqs.rows > seqs.total:
+        assert float(out_p[seqs.total:].abs().max()) == 0.0
+    back = K.unpack_rows(out_p.reshape(seqs.rows, -1), seqs).reshape(n, S, heads, 64)
+    assert _rel(back[real], out_d[real]) < 1e-5, _rel(back[real], out_d[real])
+    (back.float() * w).sum().backward()
+    assert _rel(qkv.grad[real], grad_d[real]) < 2e-3, _rel(qkv.grad[real], grad_d[real])
+    assert float(qkv.grad[~real].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("B,Kk,S,L,heads", [(2, 3, 64, 32, 2), (3, 5, 100, 32, 2), (2, 50, 512, 32, 1)])
+def test_cross_attention_over_packed_keys_equals_dense(B, Kk, S, L, heads):
+    """FiD: dense decoder queries [B, L] against the K passages of a question concatenated -- dense keys [B, K * S] (pad rows masked) vs the
+    packed buffer grouped by K (no pad rows at all)."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(B * Kk + S)
+    ids, _ = _ragged_ids(rng, B * Kk, S, 500, lo=S // 4)
+    ids_t = torch.from_numpy(ids).cuda()
+    real = ids_t != 0
+    dec, _ = _ragged_ids(rng, B, L, 500, lo=2)
+    dec_t = torch.from_numpy(dec).cuda()
+    g = torch.Generator(device="cuda").manual_seed(S)
+    q = torch.randn((B, L, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    kv = torch.randn((B * Kk, S, 2, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    out_d = K.attention_core(q, kv.reshape(B, Kk * S, 2, heads, 64), dec_t, ids_t.reshape(B, Kk * S), False)
+    w = torch.randn(out_d.shape, generator=g, device="cuda") * (dec_t != 0)[..., None, None]
+    (out_d.float() * w).sum().backward()
+    gq, gkv = q.grad.clone(), kv.grad.clone()
+    q.grad = kv.grad = None
+    seqs = K.PackedSeqs(ids_t)
+    kv_p = K.pack_rows(kv.reshape(B * Kk, S, -1), seqs).reshape(seqs.rows, 2, heads, 64)
+    out_p = K.attention_core(q, kv_p, dec_t, seqs.grouped(Kk), False)
+    dreal = dec_t != 0
+    assert _rel(out_p[dreal], out_d[dreal]) < 1e-5
+    (out_p.float() * w).sum().backward()
+    assert _rel(q.grad[dreal], gq[dreal]) < 2e-3
+    assert _rel(kv.grad[real], gkv[real]) < 2e-3 and float(kv.grad[~real].abs().max()) == 0.0
+
+
+def test_packed_attention_dropout_statistics_and_backward_consistency():
+    """With dropout the packed launch draws its own mask (keyed by the packed row), so it cannot equal the dense launch element-wise: check
+    the keep rate through the output's expectation and that forward and backward use the SAME mask (gradient of a linear functional)."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(11)
+    n, S, heads, p = 16, 128, 2, 0.25
+    ids, _ = _ragged_ids(rng, n, S, 500, lo=64)
+    seqs = K.PackedSeqs(torch.from_numpy(ids).cuda())
+    g = torch.Generator(device="cuda").manual_seed(2)
+    qkv = torch.zeros((seqs.rows, 3, heads, 64), device="cuda")
+    qkv[:, 2] = 1.0                                                               # V = 1, scores 0: every output element = (kept probability mass) / (1 - p)
+    qkv = qkv.bfloat16().requires_grad_(True)
+    out = K.attention_core(qkv, None, seqs, seqs, False, drop_p=p, seed=77)
+    o = out[:seqs.total].float()
+    assert abs(float(o.mean()) - 1.0) < 2e-2 and float(o.std()) > 1e-3
+    assert torch.equal(out, K.attention_core(qkv, None, seqs, seqs, False, drop_p=p, seed=77))
+    # d(sum out)/dV[key] = sum over queries of the dropped probability: its total equals sum(out) when V = 1
+    out.float().sum().backward()
+    dv = qkv.grad[:seqs.total, 2].float()
+    assert abs(float(dv.sum()) - float(o.sum())) / float(o.sum()) < 2e-2
+
+
+# ---- whole modules: packing ON vs OFF, and ON vs the oracle ---------------------------------------------------------------------
+def _with_packing(flag, fn):
+    from emdr2_amd.model import kernels as K
+    old = K.PACKING.enabled
+    K.PACKING.enabled = flag
+    try:
+        return fn()
+    finally:
+        K.PACKING.enabled = old
+
+
+def _grads(m):
+    out = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    return out
+
+
+def test_bert_tower_packed_equals_dense_and_oracle():
+    from emdr2_amd.model.transformer import PretrainedBertModel
+    torch.manual_seed(0)
+    m = PretrainedBertModel(_cfg(), 512)
+    rng = np.random.default_rng(0)
+    ids, _ = _ragged_ids(rng, 48, 64, 512, lo=3)
+    ids_t = torch.from_numpy(ids)
+    types = torch.zeros_like(ids_t)
+    w = torch.randn((48, CFG["hidden"]), generator=torch.Generator().manual_seed(3))
+
+    def run():
+        out = m(ids_t.cuda(), types.cuda())
+        (out.float() * w.cuda()).sum().backward()
+        return out.detach(), _grads(m)
+    out_d, g_d = _with_packing(False, run)
+    out_p, g_p = _with_packing(True, run)
+    assert _rel(out_p, out_d) < 1e-5
+    for k in g_d:
+        assert _rel(g_p[k], g_d[k]) < 2e-3, (k, _rel(g_p[k], g_d[k]))
+    P = {"bert." + k: v.detach().float().cpu().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = to.bert_embed(P, "bert", CFG, ids_t, ~to.make_attention_mask_3d(ids_t, ids_t), types)
+    assert _rel(out_p.cpu(), ref) < 2e-2
+
+
+def test_reader_packed_equals_dense():
+    from emdr2_amd.model.transformer import T5Model
+    torch.manual_seed(0)
+    m = T5Model(_cfg(), 640)
+    rng = np.random.default_rng(1)
+    enc, _ = _ragged_ids(rng, 32, 96, 640, lo=5)
+    dec, _ = _ragged_ids(rng, 32, 32, 640, lo=2)
+    enc_t, dec_t = torch.from_numpy(enc).cuda(), torch.from_numpy(dec).cuda()
+    w = torch.randn((32, 32, 640), generator=torch.Generator().manual_seed(4)).cuda() * 0.1 * (dec_t != 0)[..., None]
+
+    def run():
+        logits, e = m(enc_t, dec_t)
+        (logits.float() * w).sum().backward()
+        return logits.detach(), e.detach(), _grads(m)
+    l_d, e_d, g_d = _with_packing(False, run)
+    l_p, e_p, g_p = _with_packing(True, run)
+    real, dreal = enc_t != 0, dec_t != 0
+    assert _rel(e_p[real], e_d[real]) < 1e-5 and float(e_p[~real].abs().max()) == 0.0
+    assert _rel(l_p[dreal], l_d[dreal]) < 1e-5
+    assert set(g_p) == set(g_d)
+    for k in g_d:
+        assert _rel(g_p[k], g_d[k]) < 2e-3, (k, _rel(g_p[k], g_d[k]))
+
+
+@pytest.mark.parametrize("recompute", [False, True])
+def test_emdr2_step_packed_equals_dense(recompute):
+    """EMDR2Model.forward_assembled + the EMDR2 objective + backward: FiD over the grouped packed encoder output, the one-context pass and
+    the context tower all packed, against the dense path on the same weights (dropout 0); also under per-layer recompute."""
+    from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
+    rng = np.random.default_rng(7)
+    B, Kk, S_ret, S, L, V = 4, 8, 32, 64, 32, 640
+    torch.manual_seed(0)
+    m = EMDR2Model(None, _cfg(), V, 512, Kk, S, S_ret, cls_id=2, sep_id=3, checkpoint_activations=recompute)
+    m.train()
+    t = lambda a: torch.from_numpy(a).cuda()
+    qb = t(_ragged_ids(rng, B, S_ret, 512, lo=3)[0]); ctx = t(_ragged_ids(rng, B * Kk, S_ret, 512, lo=3)[0]).reshape(B, Kk, S_ret)
+    typ = torch.zeros_like(ctx)
+    qext, qone = t(_ragged_ids(rng, B * Kk, S, 600, lo=8)[0]), t(_ragged_ids(rng, B * Kk, S, 600, lo=8)[0])
+    dec = t(_ragged_ids(rng, B, L, 600, lo=2)[0])
+    labels = torch.roll(dec, -1, 1); labels[:, -1] = 0
+    loss_mask = (labels != 0).float()
+
+    def run():
+        q_logits = m.retriever_embedder(qb, None, torch.zeros_like(qb), "query")
+        lm, tlp, one = m.forward_assembled(q_logits, ctx, typ, qext, qone, dec)
+        loss, stats = emdr2_loss(lm, tlp, one, labels, loss_mask, eos_id=601)
+        loss.backward()
+        return loss.detach(), lm.detach(), tlp.detach(), _grads(m)
+    loss_d, lm_d, tlp_d, g_d = _with_packing(False, run)
+    loss_p, lm_p, tlp_p, g_p = _with_packing(True, run)
+    assert abs(float(loss_p) - float(loss_d)) < 1e-4 * abs(float(loss_d))
+    assert _rel(lm_p[dec != 0], lm_d[dec != 0]) < 1e-5 and _rel(tlp_p, tlp_d) < 1e-5
+    assert set(g_p) == set(g_d)
+    for k in g_d:
+        assert _rel(g_p[k], g_d[k]) < 3e-3, (k, _rel(g_p[k], g_d[k]))
