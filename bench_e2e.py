@@ -52,6 +52,8 @@ def add_args(ap):
     ap.add_argument("--keep-last-layers", default="auto",
                     help="reader-encoder layers whose activations are kept instead of re-run in the backward: a number, or 'auto' = as many as "
                          "fit the HBM left over after a first full-recompute step with 25 GB to spare (falls back to 0 on an allocation failure)")
+    ap.add_argument("--no-packing", action="store_true",
+                    help="run the encoder stacks over the reference's padded [batch, S] grids instead of the packed real tokens (A/B)")
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
                     help="BASELINE configs[5]: re-embed this many evidence rows per training step on a side stream into the spare index image "
                          "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
@@ -80,6 +82,7 @@ def setup(args, rank, world, index=None, topk=50):
     from emdr2_amd.model import kernels as Kmod
 
     B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
+    Kmod.PACKING.enabled = not getattr(args, "no_packing", False)
     if index is None:
         index = build_index(args.rows, rank, world)
     arena = EvidenceArena.synthetic(args.rows)
@@ -147,9 +150,12 @@ def choose_keep_last(ctx, world):
     free, total = torch.cuda.mem_get_info()
     capacity = free + torch.cuda.memory_reserved()            # what this process can have: its own pool + what is still free
     peak = torch.cuda.max_memory_reserved()
-    per_layer = ctx.B * ctx.K * ctx.S * H * 2 * 18           # measured: 41 GB per kept layer at B = 64, K = 50, S = 512 (16.3 tensors of [tokens, H] bf16)
+    # measured: 41 GB per kept layer at B = 64, K = 50, S = 512 padded (16.3 tensors of [tokens, H] bf16); packed: the real-token share of it
+    from emdr2_amd.model import kernels as Kmod
+    share = (Kmod.PACKING.real_tokens / Kmod.PACKING.grid_tokens) if (Kmod.PACKING.enabled and Kmod.PACKING.grid_tokens) else 1.0
+    per_layer = int(ctx.B * ctx.K * ctx.S * H * 2 * 18 * min(1.0, share * 1.15))
     n = int(1 + (capacity - (25 << 30) - peak) // per_layer) if capacity - (25 << 30) > peak else 0
-    n = max(0, min(n, 4, ctx.layers))
+    n = max(0, min(n, ctx.layers))
     if world > 1:
         t = torch.tensor([n], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
@@ -194,6 +200,8 @@ def run(ctx, steps, warmup, world):
         fence()
     ctx.keep_last, ctx.full_recompute_ms = keep, (full_ms if keep > 0 else None)
     lib.emdr2_ops_set_timing(1)
+    from emdr2_amd.model import kernels as Kmod
+    Kmod.PACKING.real_tokens = Kmod.PACKING.grid_tokens = 0
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = ctx.step()
@@ -216,6 +224,12 @@ def run(ctx, steps, warmup, world):
         "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
+                   "packed_sequences": bool(Kmod.PACKING.enabled),
+                   # encoder-stack tokens per step (query tower, context tower, reader encoder, one-context pass): real = what the packed
+                   # layout runs, padded = the reference's [batch, S] grids
+                   "tokens_real": (Kmod.PACKING.real_tokens // steps) if Kmod.PACKING.enabled else None,
+                   "tokens_padded": (Kmod.PACKING.grid_tokens // steps) if Kmod.PACKING.enabled else
+                                    ctx.B * ctx.S_ret + ctx.B * ctx.K * ctx.S_ret + 2 * ctx.B * ctx.K * ctx.S,
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (activations kept in HBM)" % ctx.keep_last if ctx.keep_last else ""),
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()),
@@ -229,8 +243,11 @@ def run(ctx, steps, warmup, world):
                      "kernel": "gemm_nt (gemm8_kernel / gemm_nt_kernel) + gemm_tn_kernel: executed flops / summed per-launch hipEvent time (rank 0)",
                      "per_step": {k: {"ms": ms[i] / steps, "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0), "launches": int(nl[i] // steps)}
                                   for i, k in enumerate(kinds)},
+                     "executed_tflop_per_step": {"gemm": gemm_fl / steps / 1e12, "attention": (fl[2] + fl[3]) / steps / 1e12},
                      "whole_step_mfu": {"tflops": fl_step * sps / 1e12, "frac": fl_step * sps / 1e12 / MFMA_PEAK_TFLOPS, "flops_per_step_per_gpu": fl_step,
-                                        "convention": "dense-GEMM flops, no recompute (SURVEY 8d)"}},
+                                        "convention": "dense-GEMM flops of the reference's PADDED grids, no recompute (SURVEY 8d): with packed sequences "
+                                                      "this is the rate at which the reference's work is retired, not the rate of executed flops "
+                                                      "(executed_tflop_per_step / ms_per_step gives that)"}},
     }
 
 

@@ -196,9 +196,9 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                 // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
                 floatx16 sacc;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 1.f;
+                for (int r = 0; r < 16; ++r) sacc[r] = (kb0 + (r & 3) + 8 * (r >> 2) + 4 * hi < sk) ? 1.f : 0.f;   // (packed: keys past sk do not exist)
                 mrun = MASKED2;
-                lrun += 32.f;
+                lrun += (float)min(32, sk - kb0);
                 dropout_and_pv(sacc);
                 continue;
             }
@@ -232,7 +232,10 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                     for (int r = 0; r < 16; ++r) {
                         const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;          // key inside the sub-block
                         const bool masked = !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
-                        const float s2 = masked ? MASKED2 : fmaf(sacc[r], sc_q, c_q);
+                        float s2 = masked ? MASKED2 : fmaf(sacc[r], sc_q, c_q);
+                        // a key past the end of a packed sequence does not exist: probability 0 even for a padded query (whose softmax is
+                        // uniform over the sk keys that do), so the forward agrees with the backward, which never stores such a key's dK / dV
+                        s2 = kb0 + kl < sk ? s2 : -3.0e38f;
                         sacc[r] = s2;
                         bmax = fmaxf(bmax, s2);
                     }

@@ -186,6 +186,7 @@ class _Packing(object):
 
     def __init__(self):
         self.enabled = True
+        self.real_tokens = self.grid_tokens = 0          # running totals over the layouts built so far (bench: tokens_real / tokens_padded)
 
 
 PACKING = _Packing()
@@ -214,6 +215,8 @@ class PackedSeqs(object):
         totals = torch.empty(2, dtype=torch.int64, device=dev)
         _native.check(lib.emdr2_seq_lengths(ids.data_ptr(), n, S, self.cu.data_ptr(), totals.data_ptr(), _sp()), "seq_lengths")
         self.total, self.pairs = (int(v) for v in totals.tolist())                  # the layout's one host sync
+        PACKING.real_tokens += self.total
+        PACKING.grid_tokens += n * S
         m = self.ROW_MULTIPLE
         self.rows = (self.total + m - 1) // m * m
         self.rowmap = torch.empty(self.rows, dtype=torch.int32, device=dev)         # packed row -> dense row (i * S + pos), -1 in the tail
@@ -650,9 +653,9 @@ class EmbeddingFn(torch.autograd.Function):
         H = W.shape[1]
         lib = _lib()
         if seqs is not None:                                     # packed rows: ids / types come from the layout, positions from its row map
-            if (types is not None) != (seqs.types is not None):
-                raise ValueError("the packed layout was built without (with) the token types this embedding call passes (omits)")
             ids, types, S = seqs.ids, seqs.types, seqs.S
+            if types is not None and T is None:
+                raise ValueError("the packed layout carries token types but no type table was passed")
             out = torch.empty((seqs.rows, H), dtype=BF16, device=ids.device)
             _native.check(lib.emdr2_embedding_packed_fwd(ids.data_ptr(), _ptr(types), seqs.rowmap.data_ptr(), w_bf16(W).data_ptr(), w_bf16(P).data_ptr(),
                                                          w_bf16(T).data_ptr() if types is not None else None, out.data_ptr(), seqs.rows, S, H,

@@ -129,7 +129,9 @@ def test_emdr2_forward_loss_and_gradients_vs_oracle():
     (lm_loss_r + r_loss_r).backward()
     one_t = one.materialize() if hasattr(one, 'materialize') else one          # OneContextLogits: the reference's tensor on demand
     assert tuple(one.shape) == tuple(one_r.shape)
-    assert _rel(lm.float().cpu(), lm_r) < 2e-2 and _rel(one_t.float().cpu(), one_r) < 2e-2
+    dreal = dec != 0          # consumed decoder positions (a padded decoder query attends uniformly over whatever keys its layout keeps; loss-masked)
+    dk = dreal[:, None, :].expand(-1, Kk, -1)
+    assert _rel(lm.float().cpu()[dreal], lm_r[dreal]) < 2e-2 and _rel(one_t.float().cpu()[dk], one_r[dk]) < 2e-2
     assert float((tlp.detach().cpu() - tlp_r.detach()).abs().max()) < 2e-2
     assert abs(float(stats["lm_loss"]) - float(lm_loss_r)) < 2e-2 * float(lm_loss_r)
     assert abs(float(stats["retriever_loss"]) - float(r_loss_r)) < 2e-2 * float(r_loss_r)
@@ -406,7 +408,7 @@ def test_flat_adam_inside_the_training_step():
     torch.manual_seed(0)
     cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05)
     m = T5Model(cfg, 512, checkpoint_activations=True).train()
-    opt = K.GRAD_SINK = FlatAdam(m, lr=1e-2, weight_decay=0.1, clip_grad=1.0, bucket_bytes=1 << 20)
+    opt = K.GRAD_SINK = FlatAdam(m, lr=1e-3, weight_decay=0.1, clip_grad=1.0, bucket_bytes=1 << 20)     # (1e-2 makes this 4-step loss curve chaotic)
     try:
         losses = []
         for step in range(4):
