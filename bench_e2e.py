@@ -154,7 +154,8 @@ def choose_keep_last(ctx, world):
     from emdr2_amd.model import kernels as Kmod
     share = (Kmod.PACKING.real_tokens / Kmod.PACKING.grid_tokens) if (Kmod.PACKING.enabled and Kmod.PACKING.grid_tokens) else 1.0
     per_layer = int(ctx.B * ctx.K * ctx.S * H * 2 * 18 * min(1.0, share * 1.15))
-    n = int(1 + (capacity - (25 << 30) - peak) // per_layer) if capacity - (25 << 30) > peak else 0
+    spare = (25 << 30) if not Kmod.PACKING.enabled else (40 << 30)     # packed: the token count (and so every activation size) moves from step to step
+    n = int(1 + (capacity - spare - peak) // per_layer) if capacity - spare > peak else 0
     n = max(0, min(n, ctx.layers))
     if world > 1:
         t = torch.tensor([n], device="cuda")
