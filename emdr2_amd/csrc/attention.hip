@@ -86,6 +86,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const int qi = q0 + l31;                       // this lane's query
     const bool qvalid = qi < sq;
     const int qc = qvalid ? qi : sq - 1;
+    const bool wave_live = q0 < sq;                 // a wave past the end of its sequence only helps to stage K / V (decoder: sq = 32 of 128)
 
     // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
     const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
@@ -140,6 +141,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this block's tiles (the only DMA in flight)
         __syncthreads();                                                          // ... from every wave; everyone is done with the other stage
         if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);
+        if (!wave_live) continue;
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * KB;
         // A block whose keys are all masked for every query of this wave contributes exp(-10000 - m) == 0 exactly once each query has
