@@ -236,6 +236,10 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     }
                     if (p.R) {
                         const uint32_t rw[4] = {rr[g].x, rr[g].y, rr[g].z, rr[g].w};
+                        // the value meets the residual as the bf16 the reference's F.linear would have stored (and as gemm8.hip, whose staging
+                        // buffer holds bf16, sees it): one rounding before the add, one after -- the same in every GEMM kernel of the library
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = bf16_to_f32(f32_to_bf16(v[j]));
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             const float r0 = bf16_to_f32((uint16_t)(rw[j] & 0xffff)), r1 = bf16_to_f32((uint16_t)(rw[j] >> 16));
@@ -276,7 +280,11 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                 if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
                 if (p.gelu) v = gelu_erf(v);
                 if (p.drop_p > 0.f) v = emdr2_keep(emdr2_row_hash(p.seed, (unsigned long long)m), (uint32_t)n, emdr2_drop_thr(p.drop_p)) ? v * emdr2_keep_scale(p.drop_p) : 0.f;
-                if (p.R) { const float rv = bf16_to_f32(((const uint16_t *)p.R)[o]); v = p.rmode == 0 ? v + rv : v * gelu_erf_grad(rv); }
+                if (p.R) {
+                    const float rv = bf16_to_f32(((const uint16_t *)p.R)[o]);
+                    if (!p.out_f32) v = bf16_to_f32(f32_to_bf16(v));          // as above: bf16 before it meets the residual
+                    v = p.rmode == 0 ? v + rv : v * gelu_erf_grad(rv);
+                }
                 if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
                 else if (p.out_f32) ((float *)p.C)[o] = v;
                 else ((uint16_t *)p.C)[o] = f32_to_bf16(v);

@@ -211,6 +211,7 @@ class PackedSeqs(object):
         dev = ids.device
         lib = _lib()
         self.n, self.S, self.max_len, self.group = n, S, S, 1
+        self.dense_ids = ids                                  # the [n, S] grid this layout was built from (consumers that want the reference's shapes)
         self.cu = torch.empty(n + 1, dtype=torch.int32, device=dev)
         totals = torch.empty(2, dtype=torch.int64, device=dev)
         _native.check(lib.emdr2_seq_lengths(ids.data_ptr(), n, S, self.cu.data_ptr(), totals.data_ptr(), _sp()), "seq_lengths")

@@ -54,10 +54,9 @@ def test_bert_tower_forward_and_backward():
     w = torch.randn(ref.shape, generator=torch.Generator().manual_seed(3))
     (out.float() * w.cuda()).sum().backward()
     (ref * w).sum().backward()
-    for k, p in m.named_parameters():
-        g_ref = P["bert." + k].grad
-        assert p.grad is not None, k
-        assert _rel(p.grad.cpu(), g_ref) < 5e-2, (k, _rel(p.grad.cpu(), g_ref))
+    for k, p in m.named_parameters():                      # every parameter receives a gradient; its VALUE is held to the bf16-faithful
+        assert p.grad is not None and P["bert." + k].grad is not None, k          # oracle in tests/test_parity_bf16_gpu.py (per tensor, two metrics)
+        assert _rel(p.grad.cpu(), P["bert." + k].grad) < 5e-2, (k, _rel(p.grad.cpu(), P["bert." + k].grad))
 
 
 def test_reader_logits_and_gradients():
@@ -80,15 +79,14 @@ def test_reader_logits_and_gradients():
     w = torch.randn(l_ref.shape, generator=torch.Generator().manual_seed(4)) * 0.1 * dreal[..., None]
     (logits.float() * w.cuda()).sum().backward()
     (l_ref * w).sum().backward()
-    worst = 0.0
     for k, p in m.named_parameters():
         g_ref = P["t5." + k].grad
         if g_ref is None:                      # e.g. token-type table: never used by the reader (t5_model.py:124-137)
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        r = _rel(p.grad.cpu(), g_ref)
-        worst = max(worst, r)
-        assert r < 6e-2, (k, r)
+        # against the plain fp32 oracle the bf16 noise of both roundings is in the difference; the sharp per-tensor comparison (two metrics,
+        # bf16-faithful oracle, the tensor's own noise as the yardstick) is tests/test_parity_bf16_gpu.py::test_reader_vs_bf16_faithful_oracle
+        assert _rel(p.grad.cpu(), g_ref) < 5e-2, (k, _rel(p.grad.cpu(), g_ref))
 
 
 def test_state_dict_keys_match_reference_fixture():

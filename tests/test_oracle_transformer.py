@@ -143,3 +143,41 @@ def test_greedy_decode_matches_the_reference_search_strategy():
     assert outs == ref
     assert len(set(map(tuple, ref))) >= 8                                # the fixture depends on the evidence, it is not one constant answer
     np.testing.assert_allclose(margins.numpy(), d["margins"], rtol=2e-2, atol=2e-4)
+
+
+def test_bf16_faithful_mode_is_pinned_on_the_fp32_oracle():
+    """The bf16-faithful form of the oracle (rounding where the HIP kernels store bf16) against the fp32 form -- itself pinned on the
+    reference above -- on the reference fixture: logits / losses / gradients differ by bf16 round-off only, weight gradients stay fp32
+    (not multiples of a bf16 ulp), and the switch leaves the fp32 form untouched."""
+    g, P0, grads, meta, passages, titles = mf.load()
+    ctx, typ, ext, one = mf.assembled_inputs(g, meta, passages, titles)
+    qb, dec = torch.from_numpy(g["e_query_ids"]), torch.from_numpy(g["e_dec_ids"])
+    labels, loss_mask = torch.from_numpy(g["e_labels"]), torch.from_numpy(g["e_loss_mask"])
+
+    def run(bf16):
+        P = {k: v.clone().requires_grad_(True) for k, v in P0.items()}
+        with to.bf16_faithful(bf16):
+            lm, tlp, oc = to.emdr2_forward(P, mf.CFG, qb, torch.zeros_like(qb), ~to.make_attention_mask_3d(qb, qb), ctx, typ, ext, one, dec)
+            loss = to.reader_ce_loss(lm, labels, loss_mask) + to.retriever_loss_and_utility(oc, tlp, labels, loss_mask, meta["eos"])[0]
+            loss.backward()
+        return lm.detach(), tlp.detach(), oc, float(loss), {k: v.grad for k, v in P.items() if v.grad is not None}
+    lm32, tlp32, oc32, loss32, g32 = run(False)
+    lmb, tlpb, ocb, lossb, gb = run(True)
+    assert not to._Mode.bf16
+    np.testing.assert_allclose(lm32.numpy(), g["e_lm_logits"], rtol=1e-4, atol=1e-4)                   # fp32 form unchanged by the switch
+    rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-12))
+    rms = lambda a, b: float((a - b).norm() / (b.norm() + 1e-12))
+    assert torch.equal(lmb, lmb.bfloat16().float()) and not torch.equal(lm32, lm32.bfloat16().float())    # outputs ARE bf16 values
+    # consumed positions (a padded decoder query averages over the keys its layout keeps: the bf16 form follows the packed layout, which
+    # does not store padded encoder rows; nothing reads such a row -- loss_mask / ignore_index 0)
+    dreal = dec != 0
+    dk = dreal[:, None, :].expand(-1, ocb.shape[1], -1)
+    assert 1e-5 < rel(lmb[dreal], lm32[dreal]) < 2e-2 and rel(ocb[dk], oc32[dk]) < 2e-2 and rel(tlpb, tlp32) < 2e-2
+    assert abs(lossb - loss32) < 1e-2 * abs(loss32)
+    gmax = max(float(v.abs().max()) for v in g32.values())
+    assert set(gb) == set(g32)
+    for k in g32:
+        assert float((gb[k] - g32[k]).abs().max()) < 5e-2 * max(float(g32[k].abs().max()), 1e-2 * gmax), k
+        assert rms(gb[k], g32[k]) < 5e-2 or float(g32[k].abs().max()) < 1e-2 * gmax, (k, rms(gb[k], g32[k]))
+    w = gb["language_model.language_model.encoder.layers.0.mlp.dense_h_to_4h.weight"]
+    assert not torch.equal(w, w.bfloat16().float())                                                     # weight gradients are fp32
