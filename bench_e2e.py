@@ -211,10 +211,16 @@ def run(ctx, steps, warmup, world):
     ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); nl = (ctypes.c_int64 * 4)()
     _native.check(lib.emdr2_ops_timing_collect(ms, fl, nl, 4), "ops_timing_collect")
     lib.emdr2_ops_set_timing(0)
+    replicas = None
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
+        # data-parallel replicas must hold bit-identical parameters after the timed steps (same averaged gradients, deterministic norm)
+        cs = torch.stack([b["master"].double().sum() for b in ctx.opt.buckets]).sum().reshape(1)
+        allcs = [torch.empty_like(cs) for _ in range(world)]
+        torch.distributed.all_gather(allcs, cs)
+        replicas = [float(c.item()) for c in allcs]
     fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)
     sps = steps / elapsed
     gemm_ms, gemm_fl = ms[0] + ms[1], fl[0] + fl[1]
@@ -233,7 +239,7 @@ def run(ctx, steps, warmup, world):
                                     ctx.B * ctx.S_ret + ctx.B * ctx.K * ctx.S_ret + 2 * ctx.B * ctx.K * ctx.S,
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (activations kept in HBM)" % ctx.keep_last if ctx.keep_last else ""),
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
-                   "loss": float(loss.detach()),
+                   "loss": float(loss.detach()), "replica_parameter_checksums": replicas,
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
                    "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
                    "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
@@ -252,7 +258,7 @@ def run(ctx, steps, warmup, world):
     }
 
 
-def cpu_baseline_subprocess(seconds=15.0, limit=120.0):
+def cpu_baseline_subprocess(seconds=12.0, limit=120.0):
     """cpu_baseline_model in a child process with a hard wall-clock limit (a slow host must not cost the benchmark its JSON line)."""
     import subprocess
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
@@ -266,11 +272,11 @@ def cpu_baseline_subprocess(seconds=15.0, limit=120.0):
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
 
 
-def cpu_baseline_model(seconds=20.0, layers=2, max_threads=64):
+def cpu_baseline_model(seconds=20.0, layers=12, max_threads=64):
     """The model path on the host cores: the torch-fp32 oracle restatement of the reference's forward / loss (oracle.transformer_oracle,
-    pinned on the reference's modules) + autograd backward at the BASELINE layer shapes (H = 768, 12 heads, FFN 3072, S_ret 256, S 512, L 32,
-    full vocabularies) on a BOUNDED sample -- B = 1, K = 2 and `layers` of the 12 layers of every stack -- with the rate scaled by dense-GEMM
-    flops to the 12-layer B = 64, K = 50 step.  kind "port".  The thread count is capped (tiny GEMMs on hundreds of threads run slower)."""
+    pinned on the reference's modules) + autograd backward at the BASELINE architecture (all 12 layers of every stack, H = 768, 12 heads,
+    FFN 3072, S_ret 256, S 512, L 32, full vocabularies) on a BOUNDED sample -- B = 1 question, K = 2 passages -- so the factor to the
+    B = 64, K = 50 step is batch only (dense-GEMM flops).  kind "port".  Threads: the faster of 32 / `max_threads` on the first steps."""
     from oracle import transformer_oracle as to
     cores = min(os.cpu_count() or 1, max_threads)
     torch.set_num_threads(cores)
@@ -294,15 +300,25 @@ def cpu_baseline_model(seconds=20.0, layers=2, max_threads=64):
         loss = to.reader_ce_loss(lm, labels, mask) + to.retriever_loss_and_utility(oc, tlp, labels, mask, 30523)[0]
         loss.backward()
     t0 = time.perf_counter(); step(); t_first = time.perf_counter() - t0          # includes allocator warm-up
+    tried = {cores: None}
+    if cores > 32:                                                                # one step at 32 threads: keep whichever count is faster
+        t0 = time.perf_counter(); step(); tried[cores] = time.perf_counter() - t0
+        torch.set_num_threads(32)
+        step()
+        t0 = time.perf_counter(); step(); tried[32] = time.perf_counter() - t0
+        cores = min(tried, key=tried.get)
+        torch.set_num_threads(cores)
     reps, t = 0, 0.0
-    while reps < 1 or (t + t_first + t / max(reps, 1) < seconds and reps < 5):
+    spent = time.perf_counter()
+    while reps < 1 or (t / reps * (reps + 1) + t_first + sum(v or 0 for v in tried.values()) * 1.5 < seconds and reps < 3):
         t0 = time.perf_counter(); step(); t += time.perf_counter() - t0; reps += 1
     per = t / reps
     scale = flops_per_step(64, 50, S_ret, S, L, H, V_T5, 12) / flops_per_step(B, K, S_ret, S, L, H, V_T5, layers)
     return {"value": 1.0 / (per * scale), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": "%d step(s) of the fp32 oracle (forward + loss + autograd backward, Adam excluded) at B=%d, K=%d, S_ret %d, S %d, L %d, "
-                      "%d of 12 layers per stack, torch CPU, %d threads: %.2f s/step; scaled x%.0f by dense-GEMM flops to 12 layers, B=64, K=50"
-                      % (reps, B, K, S_ret, S, L, layers, cores, per, scale)}
+                      "%d of 12 layers per stack, torch CPU, %d threads (tried: %s): %.2f s/step; scaled x%.0f by dense-GEMM flops to B=64, K=50"
+                      % (reps, B, K, S_ret, S, L, layers, cores, ", ".join("%d -> %s" % (k, "%.2f s" % v if v else "first") for k, v in sorted(tried.items())),
+                         per, scale)}
 
 
 def main():
@@ -320,14 +336,8 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_model(args.cpu_seconds)), flush=True)
         return
-    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
-    if os.environ.get("EMDR2_SINGLE_DEVICE"):          # dry run of the N-rank code path on a 1-GPU box: all ranks share cuda:0 (use with gloo)
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")
-        torch.distributed.init_process_group(backend=backend, **({"device_id": torch.device("cuda", local_rank)} if backend == "nccl" else {}))
+    from emdr2_amd import dist_util
+    rank, world, _ = dist_util.init_distributed()
     ctx = setup(args, rank, world, topk=args.topk)
     res = run(ctx, args.steps, args.warmup, world)
     if rank == 0:
@@ -337,8 +347,7 @@ def main():
         if args.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_subprocess()
         print(json.dumps(out), flush=True)
-    if world > 1:
-        torch.distributed.destroy_process_group()
+    dist_util.shutdown()
 
 
 if __name__ == "__main__":

@@ -132,7 +132,6 @@ def _read(load_dir, want_release=False):
     if iteration == 0 and not release:
         return (None, 0, False) if want_release else (None, 0)
     state = torch.load(get_checkpoint_name(load_dir, iteration, release), map_location='cpu', weights_only=False)
-    _check_version(state)
     return (state, iteration, release) if want_release else (state, iteration)
 
 
@@ -151,6 +150,9 @@ def load_checkpoint(load_dir, model, optimizer=None, lr_scheduler=None):
     state, iteration, release = _read(load_dir, want_release=True)
     if state is None:
         return 0
+    # only this path consults the version, like the reference (checkpointing.py:202 -> set_checkpoint_version): its pretrained-model loaders
+    # (:267-340) never do, so a pretrained T5 / DPR file without the key is read in the version-1.0 row order there and here
+    _check_version(state)
     load_emdr2_state_dict(model, state['model'])
     _invalidate_weight_caches()
     if release:

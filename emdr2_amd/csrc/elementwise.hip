@@ -906,10 +906,12 @@ extern "C" int emdr2_dropout(const void *x, void *out, int64_t n, int cols, floa
 }
 
 // ---- retriever prior (emdr2_model.py:134-145): sim[b, k] = <q[b], c[b, k]> * scale, log-softmax over the K retrieved passages --------------------
-// One workgroup per question; K <= 128 (top-k 50 / 100 + 1).  q, c bf16, everything else fp32.  prob (= exp(logp)) is kept for the backward.
+// One workgroup per question; K <= 1024 (top-k 50 / 100 + 1 in the shipped scripts).  q, c bf16, everything else fp32.  prob (= exp(logp)) is
+// kept for the backward.
+#define PRIOR_MAX_K 1024
 __global__ void __launch_bounds__(256) retriever_prior_fwd_kernel(const uint16_t *q, const uint16_t *c, float *logp, float *prob, int K, int H, float scale)
 {
-    __shared__ float sim[128];
+    __shared__ float sim[PRIOR_MAX_K];
     __shared__ float stat[2];
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint16_t *qb = q + (long long)b * H;
@@ -928,9 +930,11 @@ __global__ void __launch_bounds__(256) retriever_prior_fwd_kernel(const uint16_t
     }
     __syncthreads();
     if (wave == 0) {
-        const float a = lane < K ? sim[lane] : -3.0e38f, a2 = lane + 64 < K ? sim[lane + 64] : -3.0e38f;
-        const float m = wave_max(fmaxf(a, a2));
-        const float e = (lane < K ? __expf(a - m) : 0.f) + (lane + 64 < K ? __expf(a2 - m) : 0.f);
+        float a = -3.0e38f;
+        for (int k = lane; k < K; k += 64) a = fmaxf(a, sim[k]);
+        const float m = wave_max(a);
+        float e = 0.f;
+        for (int k = lane; k < K; k += 64) e += __expf(sim[k] - m);
         const float l = wave_sum(e);
         if (lane == 0) { stat[0] = m; stat[1] = __logf(l); }
     }
@@ -946,12 +950,14 @@ __global__ void __launch_bounds__(256) retriever_prior_fwd_kernel(const uint16_t
 __global__ void __launch_bounds__(256) retriever_prior_bwd_kernel(const float *g, const float *prob, const uint16_t *q, const uint16_t *c, uint16_t *dq,
                                                                   uint16_t *dc, int K, int H, float scale)
 {
-    __shared__ float dsim[128];
+    __shared__ float dsim[PRIOR_MAX_K];
     __shared__ float gsum;
     const int b = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float *gb = g + (long long)b * K, *pb = prob + (long long)b * K;
     if (wave == 0) {
-        const float t = wave_sum((lane < K ? gb[lane] : 0.f) + (lane + 64 < K ? gb[lane + 64] : 0.f));
+        float t = 0.f;
+        for (int k = lane; k < K; k += 64) t += gb[k];
+        t = wave_sum(t);
         if (lane == 0) gsum = t;
     }
     __syncthreads();
@@ -1018,7 +1024,8 @@ __global__ void __launch_bounds__(256) lse_combine_kernel(const float *pmax, con
 
 extern "C" int emdr2_retriever_prior_fwd(const void *q, const void *c, float *logp, float *prob, int batch, int K, int H, float scale, void *stream)
 {
-    if (!q || !c || !logp || !prob || batch < 1 || K < 1 || K > 128 || H < 8 || (H & 7) || ((uintptr_t)q & 15) || ((uintptr_t)c & 15)) return -1;
+    if (!q || !c || !logp || !prob || batch < 1 || K < 1 || H < 8 || (H & 7) || ((uintptr_t)q & 15) || ((uintptr_t)c & 15)) return -1;
+    if (K > PRIOR_MAX_K) return -4;
     hipLaunchKernelGGL(retriever_prior_fwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)q, (const uint16_t *)c, logp, prob, K,
                        H, scale);
     return LAUNCH_OK();
@@ -1027,7 +1034,8 @@ extern "C" int emdr2_retriever_prior_fwd(const void *q, const void *c, float *lo
 extern "C" int emdr2_retriever_prior_bwd(const float *dlogp, const float *prob, const void *q, const void *c, void *dq, void *dc, int batch, int K, int H,
                                          float scale, void *stream)
 {
-    if (!dlogp || !prob || !q || !c || (!dq && !dc) || batch < 1 || K < 1 || K > 128 || H < 8) return -1;
+    if (!dlogp || !prob || !q || !c || (!dq && !dc) || batch < 1 || K < 1 || H < 8) return -1;
+    if (K > PRIOR_MAX_K) return -4;
     hipLaunchKernelGGL(retriever_prior_bwd_kernel, dim3(batch), dim3(256), 0, (hipStream_t)stream, dlogp, prob, (const uint16_t *)q, (const uint16_t *)c,
                        (uint16_t *)dq, (uint16_t *)dc, K, H, scale);
     return LAUNCH_OK();

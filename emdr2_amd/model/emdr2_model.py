@@ -188,7 +188,8 @@ class EMDR2Model(torch.nn.Module):
                 all_query_context_hidden_states=None, all_query_context_ids_unflat=None, topk_log_probs=None):
         """Training mode: (lm_logits, topk_log_probs, lm_logits_one_context).  Eval mode (emdr2_model.py:211-214): (lm_logits,
         topk_log_probs, all_query_context_hidden_states [B, K*S, H], all_query_context_ids_unflat [B, K*S]); passing the last two back
-        in skips retrieval and the encoder, which is how the greedy decoder iterates (search_strategy.py:203-213)."""
+        in skips retrieval and the encoder, which is how the greedy decoder iterates (search_strategy.py:203-213).  `dec_ids=None` (eval
+        mode only, not in the reference) runs retrieval + encoder without a decoder pass: lm_logits is None."""
         if all_query_context_hidden_states is not None:
             lm_logits = self.language_model.decode(dec_ids, all_query_context_hidden_states, all_query_context_ids_unflat)
             return lm_logits, topk_log_probs, all_query_context_hidden_states, all_query_context_ids_unflat
@@ -216,12 +217,14 @@ class EMDR2Model(torch.nn.Module):
             # the reader encoder over real tokens only; a question's K passages are consecutive sequences of the packed buffer, so the FiD
             # concatenation (:159-161) is the same rows seen as B groups of K sequences -- no pad rows between the passages
             enc, seqs = self.language_model.encode_packed(qext)
-            lm_logits = self.language_model.decode(dec_ids, enc, seqs.grouped(Kk))
+            lm_logits = self.language_model.decode(dec_ids, enc, seqs.grouped(Kk)) if dec_ids is not None else None
         else:
             enc = self.language_model.encode(qext).reshape(B, Kk * S, H)                      # K passages concatenated (FiD), :148-164
-            lm_logits = self.language_model.decode(dec_ids, enc, qext.reshape(B, Kk * S))       # :166-183
+            lm_logits = self.language_model.decode(dec_ids, enc, qext.reshape(B, Kk * S)) if dec_ids is not None else None   # :166-183
 
         one = None
+        if dec_ids is None and self.training:
+            raise ValueError("dec_ids=None (encoder only) is an evaluation-mode call")
         if self.training and self.update_retriever:
             with torch.no_grad():                                                             # :185-210
                 dec_rep = torch.repeat_interleave(dec_ids, Kk, dim=0)

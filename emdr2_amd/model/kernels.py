@@ -752,7 +752,9 @@ def lm_head_gold_logprob(hidden, weight, bias, labels):
     dev = hidden.device
     pmax = torch.empty((M, slots), dtype=torch.float32, device=dev)
     psum = torch.empty_like(pmax)
-    gold = torch.empty(M, dtype=torch.float32, device=dev)
+    # the epilogue writes gold[row] only when the label falls on one of the V columns: zero-initialised, so a label outside [0, V) (an
+    # ignore_index such as -100) yields gold = 0 - logsumexp instead of whatever the allocator handed out; callers mask such rows anyway
+    gold = torch.zeros(M, dtype=torch.float32, device=dev)
     out = torch.empty_like(gold)
     _native.check(_lib().emdr2_gemm_nt_lse_bf16(h2.data_ptr(), H, w_bf16(weight).data_ptr(), H, M, V, H, 1.0, _ptr(bias.detach() if bias is not None else None),
                                                 lab.data_ptr(), pmax.data_ptr(), psum.data_ptr(), gold.data_ptr(), _sp()), "gemm_nt_lse")

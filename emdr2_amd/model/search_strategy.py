@@ -15,8 +15,9 @@ from emdr2_amd.model.transformer import cross_kv_cache
 
 
 class SampleOrGreedySearch(object):
-    def __init__(self, max_decode_len, bos_id, eos_id, sample=False, topk_evidence=-1, incremental=True):
+    def __init__(self, max_decode_len, bos_id, eos_id, sample=False, topk_evidence=-1, incremental=True, keep_logits=False):
         self.max_decode_length, self.bos_id, self.eos_id, self.sample, self.incremental = max_decode_len, bos_id, eos_id, sample, incremental
+        self.keep_logits = keep_logits         # tests only: hold every step's [b, V] logits in `last_logits` (compares the two decoding forms)
         assert topk_evidence >= 1, "this code is customized for retrieval tasks"
         if sample:
             raise NotImplementedError("sampling is not used by the reference's evaluation scripts (--beam-size 1 -> greedy)")
@@ -29,11 +30,16 @@ class SampleOrGreedySearch(object):
         eos_flags = np.zeros((batch,), dtype=np.int32)
         result = []
         hidden = ids_unflat = topk_log_probs = None
-        self.last_logits = []                                               # [b, V] per step (tests compare the two decoding forms)
+        self.last_logits = []
         with torch.no_grad(), cross_kv_cache(model):
             state = None
             for i in range(L):
-                if i == 0 or not self.incremental:
+                if i == 0 and self.incremental:
+                    # retrieval + assembly + reader encoder only (dec_ids None: no decoder pass -- the reference's first call decodes the whole
+                    # block and this loop would then redo position 0); the decoder runs position by position below
+                    _, topk_log_probs, hidden, ids_unflat = model(query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5,
+                                                                  query_ids_t5_len, None)
+                elif not self.incremental:
                     logits, topk_log_probs, hidden, ids_unflat = model(query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5,
                                                                        query_ids_t5_len, y_block, all_query_context_hidden_states=hidden,
                                                                        all_query_context_ids_unflat=ids_unflat, topk_log_probs=topk_log_probs)
@@ -45,7 +51,8 @@ class SampleOrGreedySearch(object):
                         y_pad = torch.zeros((batch, state["len"]), dtype=torch.int64, device=y_block.device)
                     y_pad[:, :L] = y_block
                     step_logits = reader.decode_step(y_block[:, i:i + 1].contiguous(), i, y_pad, hidden, ids_unflat, state)[:, 0, :]
-                self.last_logits.append(step_logits.float())
+                if self.keep_logits:
+                    self.last_logits.append(step_logits.float())
                 ys = torch.argmax(step_logits.float(), dim=1)             # argmax of log_softmax == argmax of the logits
                 if i + 1 < L:
                     y_block[:, i + 1] = ys

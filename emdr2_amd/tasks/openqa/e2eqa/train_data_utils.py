@@ -11,31 +11,27 @@ import torch
 
 
 def build_tokens_types_paddings_from_ids(src_ids, answer_text_ids, max_seq_length, decoder_seq_length, cls_id, sep_id, pad_id, bos_id, eos_id):
-    enc_ids = [cls_id] + list(src_ids)
-    tokentypes_enc = [0] * len(enc_ids)
-    if len(enc_ids) > max_seq_length - 1:
-        enc_ids = enc_ids[0: max_seq_length - 1]
-        tokentypes_enc = tokentypes_enc[0: max_seq_length - 1]
-    enc_ids.append(sep_id)
-    tokentypes_enc.append(0)
-    num_tokens_enc = len(enc_ids)
-    padding_length = max_seq_length - len(enc_ids)
-    if padding_length > 0:
-        enc_ids.extend([pad_id] * padding_length)
-        tokentypes_enc.extend([pad_id] * padding_length)
+    """The reference's item layout (tasks/openqa/e2eqa/train_data_utils.py:27-81; pinned by tests/golden/a1_ref.npz) as array fills:
+    encoder row = [CLS] question [SEP] then padding, the question cut so that both markers fit; its token types are 0 on the tokens and --
+    like the reference -- `pad_id` on the padding; decoder input = [BOS] answer, labels = answer [EOS], both cut to the decoder length and
+    padded; loss_mask marks the decoder-input positions that hold a token.  Returns python lists and the encoder token count."""
+    S, L = int(max_seq_length), int(decoder_seq_length)
+    question = np.asarray(list(src_ids), dtype=np.int64)[:max(S - 2, 0)]
+    n_enc = question.size + 2
+    enc = np.full(max(S, n_enc), pad_id, dtype=np.int64)
+    enc[0], enc[1:n_enc - 1], enc[n_enc - 1] = cls_id, question, sep_id
+    types = np.where(np.arange(enc.size) < n_enc, 0, pad_id)
 
-    dec_in_ids, dec_out_ids = [bos_id] + list(answer_text_ids), list(answer_text_ids)
-    if len(dec_in_ids) > decoder_seq_length:
-        dec_in_ids = dec_in_ids[0: decoder_seq_length]
-        dec_out_ids = dec_out_ids[0: decoder_seq_length - 1]
-    dec_out_ids.append(eos_id)
-    num_tokens_dec = len(dec_in_ids)
-    padding_length_dec = decoder_seq_length - num_tokens_dec
-    assert padding_length_dec >= 0
-    dec_in_ids.extend([pad_id] * padding_length_dec)
-    dec_out_ids.extend([pad_id] * padding_length_dec)
-    loss_mask = ([1] * num_tokens_dec) + ([0] * padding_length_dec)
-    return enc_ids, tokentypes_enc, num_tokens_enc, dec_in_ids, dec_out_ids, loss_mask
+    answer = np.asarray(list(answer_text_ids), dtype=np.int64)[:max(L - 1, 0)]
+    n_dec = answer.size + 1
+    if n_dec > L:
+        raise AssertionError("decoder_seq_length must hold at least [BOS]")
+    dec_in = np.full(L, pad_id, dtype=np.int64)
+    labels = np.full(L, pad_id, dtype=np.int64)
+    dec_in[0], dec_in[1:n_dec] = bos_id, answer
+    labels[:answer.size], labels[answer.size] = answer, eos_id
+    loss_mask = (np.arange(L) < n_dec).astype(np.int64)
+    return enc.tolist(), types.tolist(), n_enc, dec_in.tolist(), labels.tolist(), loss_mask.tolist()
 
 
 def build_sample(query_uid, question_ids, answer_ids, seq_length_ret, decoder_seq_length, cls_id, sep_id, pad_id, bos_id, eos_id, reference=None):

@@ -16,15 +16,9 @@ def initialize(argv=None):
     if not torch.cuda.is_available():
         from emdr2_amd import _native
         raise _native.NativeError("the QA task needs a GPU; there is no CPU fallback")
-    if os.environ.get("EMDR2_SINGLE_DEVICE"):                          # dry run of the N-rank path on a 1-GPU box (all ranks on cuda:0, gloo)
-        args.local_rank = 0
-    torch.cuda.set_device(args.local_rank)
-    if args.world_size > 1 and not torch.distributed.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "6000")
-        backend = os.environ.get("EMDR2_DIST_BACKEND", "nccl")         # "nccl" is RCCL on ROCm
-        extra = {"device_id": torch.device("cuda", args.local_rank)} if backend == "nccl" else {}
-        torch.distributed.init_process_group(backend=backend, world_size=args.world_size, rank=args.rank, **extra)
+    from emdr2_amd import dist_util
+    _, _, dev = dist_util.init_distributed(rank=args.rank, world=args.world_size, local_rank=args.local_rank)     # one process per GPU, RCCL
+    args.local_rank = dev.index
     from emdr2_amd.model import kernels
     kernels.DROPOUT.base_seed = args.seed                                # megatron/initialize.py:_set_random_seed: same seed on all DP ranks
     torch.manual_seed(args.seed)

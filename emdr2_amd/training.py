@@ -40,68 +40,6 @@ class AnnealingLR(object):
         self.num_iters = sd['num_iters']
 
 
-class FusedAdam(object):
-    """Adam with decoupled weight decay on fp32 masters (apex FusedAdam(adam_w_mode=True) defaults betas (0.9, 0.999), eps 1e-8;
-    SURVEY.md 8c: apex is unpinned in the reference, this is the documented choice), global-norm clipping folded into the update."""
-
-    def __init__(self, param_groups, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad=1.0):
-        self.groups = [dict(g) for g in param_groups]
-        for g in self.groups:
-            g.setdefault("weight_decay", weight_decay)
-        self.lr, self.betas, self.eps, self.clip_grad, self.step_count = lr, betas, eps, clip_grad, 0
-        self.state = {}
-
-    def zero_grad(self):
-        for g in self.groups:
-            for p in g["params"]:
-                p.grad = None
-        from emdr2_amd.model import kernels
-        kernels.ATTN_STASH.store.clear()      # entries of a forward whose backward never ran must not outlive the step
-
-    def state_dict(self):
-        """Moments in parameter order (torch-optimizer style: {'step', 'state': {index: {'exp_avg', 'exp_avg_sq'}}})."""
-        params = [p for g in self.groups for p in g["params"]]
-        return {'step': self.step_count,
-                'state': {i: {'exp_avg': self.state[p][0], 'exp_avg_sq': self.state[p][1]} for i, p in enumerate(params) if p in self.state}}
-
-    def load_state_dict(self, sd):
-        params = [p for g in self.groups for p in g["params"]]
-        self.step_count = sd['step']
-        for i, st in sd['state'].items():
-            p = params[int(i)]
-            self.state[p] = (st['exp_avg'].to(p.device, torch.float32).clone(), st['exp_avg_sq'].to(p.device, torch.float32).clone())
-        from emdr2_amd.model import kernels
-        kernels.DROPOUT.step = self.step_count
-
-    def step(self, lr=None):
-        lib = _native.lib()
-        sp = _native.stream_ptr()
-        lr = self.lr if lr is None else lr
-        self.step_count += 1
-        params = [p for g in self.groups for p in g["params"] if p.grad is not None]
-        if not params:
-            return 0.0
-        gsq = torch.zeros(1, dtype=torch.float32, device=params[0].device)
-        if getattr(self, "_scratch", None) is None:
-            self._scratch = torch.zeros(1025, dtype=torch.float32, device=params[0].device)
-        for p in params:
-            _native.check(lib.emdr2_sumsq_f32(p.grad.data_ptr(), p.grad.numel(), gsq.data_ptr(), self._scratch.data_ptr(), sp), "sumsq")
-        for g in self.groups:
-            for p in g["params"]:
-                if p.grad is None:
-                    continue
-                st = self.state.get(p)
-                if st is None:
-                    st = self.state[p] = (torch.zeros_like(p), torch.zeros_like(p))
-                _native.check(lib.emdr2_adam_step(p.data_ptr(), p.grad.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), None, p.numel(), lr,
-                                                  self.betas[0], self.betas[1], self.eps, g["weight_decay"], self.step_count, gsq.data_ptr(),
-                                                  self.clip_grad, sp), "adam_step")
-        from emdr2_amd.model import kernels
-        kernels.WEIGHTS.invalidate()      # masters were written through raw pointers: bf16 working copies are rebuilt lazily
-        kernels.DROPOUT.step = self.step_count   # next iteration draws fresh dropout masks
-        return gsq
-
-
 def allreduce_gradients(module, group=None):
     """LocalDDP.allreduce_params (megatron/model/distributed.py:35-62): one flattened all-reduce of every gradient, pre-divided by the
     data-parallel world size.  RCCL over xGMI on the GPU box, gloo in the CPU tests."""
@@ -123,107 +61,6 @@ def allreduce_gradients(module, group=None):
         off += n
 
 
-class GradientBuckets(object):
-    """Data-parallel gradient averaging, bucketed and overlapped with the backward (the reference does one blocking flattened
-    all-reduce after the backward, megatron/model/distributed.py:35-62).
-
-    Parameters are laid out, in reverse registration order (roughly the order their gradients become final), into flat fp32 buckets;
-    `p.grad` is a view into its bucket, so nothing is copied before or after the collective.  The autograd functions hand every gradient
-    to `accumulate`; once a bucket has received the last expected contribution of each of its parameters it is pre-divided by the world
-    size and all-reduced asynchronously (RCCL over xGMI on the GPU box: the collective runs on the communicator's stream while the
-    backward keeps computing), `finish()` waits for the handles.  How many contributions a parameter receives per step (1, or more for
-    the tied embedding / LM-head weights) is learned in the first step, during which all buckets are reduced in `finish()`.
-    Result = `allreduce_gradients` (tests/test_dist_allreduce.py, gloo, world size 2)."""
-
-    def __init__(self, params, group=None, bucket_bytes=128 << 20):
-        self.group = group
-        self.params = [p for p in params if p.requires_grad][::-1]
-        self.buckets, self.bucket_of, self.view = [], {}, {}
-        cur, cur_n = [], 0
-        for p in self.params:
-            if cur and (cur_n + p.numel()) * 4 > bucket_bytes:
-                self._close(cur)
-                cur, cur_n = [], 0
-            cur.append(p); cur_n += p.numel()
-        if cur:
-            self._close(cur)
-        self.expected = None                  # {param: contributions per step}, learned in the first step
-        self.count = {p: 0 for p in self.params}
-        self.launched_early = 0
-        self.begin_step()
-
-    def _close(self, plist):
-        dev = plist[0].device
-        flat = torch.zeros(sum(p.numel() for p in plist), dtype=torch.float32, device=dev)
-        b = {"params": plist, "flat": flat, "pending": 0, "handle": None, "launched": False}
-        off = 0
-        for p in plist:
-            self.view[p] = flat[off:off + p.numel()].view(p.shape)
-            self.bucket_of[p] = b
-            off += p.numel()
-        self.buckets.append(b)
-
-    def _world(self):
-        if torch.distributed.is_available() and torch.distributed.is_initialized():
-            return torch.distributed.get_world_size(self.group)
-        return 1
-
-    def owns(self, p):
-        return p in self.view
-
-    def begin_step(self):
-        """After optimizer.zero_grad(): clear the buckets and the per-step bookkeeping."""
-        for b in self.buckets:
-            b["flat"].zero_()
-            b["handle"], b["launched"] = None, False
-            b["pending"] = sum(1 for p in b["params"] if self.expected and self.expected.get(p, 0) > 0)
-        for p in self.params:
-            self.count[p] = 0
-            p.grad = None
-
-    def accumulate(self, p, g):
-        b = self.bucket_of[p]
-        if b["launched"]:
-            raise RuntimeError("gradient for a parameter whose bucket was already reduced (the contribution pattern changed between steps)")
-        v = self.view[p]
-        if self.count[p] == 0:
-            v.copy_(g.view_as(v))
-            p.grad = v
-        else:
-            v.add_(g.view_as(v))
-        self.count[p] += 1
-        if self.expected is not None:
-            exp = self.expected.get(p, 0)
-            if exp == 0 or self.count[p] > exp:
-                raise RuntimeError("unexpected gradient contribution (the contribution pattern changed between steps)")
-            if self.count[p] == exp:
-                b["pending"] -= 1
-                if b["pending"] == 0:
-                    self._launch(b)
-                    self.launched_early += 1
-
-    def _launch(self, b):
-        b["launched"] = True
-        world = self._world()
-        if world > 1:
-            b["flat"].div_(world)                                          # pre-divide, then sum (distributed.py:56-58)
-            b["handle"] = torch.distributed.all_reduce(b["flat"], group=self.group, async_op=True)
-
-    def finish(self):
-        """After loss.backward(): reduce what is left, wait for everything."""
-        if self.expected is None:
-            self.expected = dict(self.count)
-        elif any(self.count[p] != self.expected.get(p, 0) for p in self.params):
-            raise RuntimeError("gradient contributions differ from the first step")
-        for b in self.buckets:
-            if not b["launched"] and any(self.count[p] for p in b["params"]):
-                self._launch(b)
-        for b in self.buckets:
-            if b["handle"] is not None:
-                b["handle"].wait()
-                b["handle"] = None
-
-
 class FlatAdam(object):
     """The optimizer step AND the data-parallel gradient exchange over FLAT buckets (the reference: apex FusedAdam through
     amp_C.multi_tensor_apply on fp32 masters, fp16/fp16.py:332-354,420-474; global-norm clip via amp_C.multi_tensor_l2norm, mpu/grads.py:74-127;
@@ -240,12 +77,21 @@ class FlatAdam(object):
     cast to bf16, all-reduced asynchronously (RCCL over xGMI: 0.88 GB on the wire per step like the reference's fp16 buffer, half of an fp32
     exchange) while the backward keeps computing, and widened back to fp32 in `finish()`.  Every rank receives the same all-reduced bf16 values
     and the global norm is summed deterministically (block partials in index order, buckets in launch order), so replicas stay bit-identical.
+    `exchange_dtype="fp32"` all-reduces the fp32 buckets themselves instead (twice the bytes; 24 mantissa bits where bf16 has 8 and the
+    reference's fp16 buffer 11 -- the choice is numerics against wire time, the default follows the reference's 16 bits).
+    Which parameters receive how many contributions is learned in the first step; if a later step deviates (a branch of the model switched
+    on or off), nothing is lost: a contribution that arrives after its bucket left is collected in a side buffer and all-reduced in
+    `finish()`, and the pattern is re-learned from that step.
 
     Parameters that never receive a gradient (the reader's unused token-type table) are left untouched, like apex / torch skip `grad is None`."""
 
-    def __init__(self, module, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad=1.0, group=None, bucket_bytes=512 << 20):
+    def __init__(self, module, lr=2e-5, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.1, clip_grad=1.0, group=None, bucket_bytes=512 << 20,
+                 exchange_dtype="bf16"):
         from emdr2_amd.model import kernels
+        if exchange_dtype not in ("bf16", "fp32"):
+            raise ValueError("exchange_dtype must be 'bf16' or 'fp32'")
         self.lr, self.betas, self.eps, self.weight_decay, self.clip_grad, self.group = lr, betas, eps, weight_decay, clip_grad, group
+        self.exchange_dtype, self.pattern_changes = exchange_dtype, 0
         self.step_count = 0
         no_decay = set(id(p) for n, p in module.named_parameters() if (n.endswith(".bias") or "layernorm" in n))      # model/utils.py:64-83
         self.params = [p for p in module.parameters() if p.requires_grad][::-1]
@@ -261,6 +107,12 @@ class FlatAdam(object):
         if cur:
             self._close(cur, no_decay)
         dev = self.params[0].device
+        # Host tensors: only the gradient-sink / exchange bookkeeping below runs (torch.distributed plumbing, fp32 exchange) -- that is how
+        # the N-rank logic is exercised over gloo without a GPU (tests/test_dist_allreduce.py).  There is no host optimizer: step() raises.
+        self.on_device = dev.type == "cuda"
+        if not self.on_device and exchange_dtype != "fp32":
+            raise _native.NativeError("FlatAdam on host tensors is the exchange bookkeeping only: exchange_dtype must be 'fp32' (the bf16 "
+                                      "exchange and the optimizer step are HIP kernels)")
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = torch.zeros(1025, dtype=torch.float32, device=dev)
         self.expected = None                  # {param: contributions per step}, learned in the first step
@@ -285,7 +137,8 @@ class FlatAdam(object):
                 split = off
         f32 = lambda: torch.zeros(off, dtype=torch.float32, device=dev)
         b = {"params": ordered, "n": off, "split": split, "master": f32(), "grad": f32(), "m": f32(), "v": f32(),
-             "work": torch.zeros(off, dtype=torch.bfloat16, device=dev), "xchg": None, "pending": 0, "handle": None, "launched": False}
+             "work": torch.zeros(off, dtype=torch.bfloat16, device=dev), "xchg": None, "late": None, "pending": 0, "handle": None,
+             "launched": False}
         for p, o in zip(ordered, offs):
             n = p.numel()
             b["master"][o:o + n].view(p.shape).copy_(p.data)
@@ -314,6 +167,8 @@ class FlatAdam(object):
         return view
 
     def refresh_working_copies(self):
+        if not self.on_device:
+            return
         lib, sp = _native.lib(), _native.stream_ptr()
         for b in self.buckets:
             _native.check(lib.emdr2_cast_f32_to_bf16(b["master"].data_ptr(), b["work"].data_ptr(), b["n"], sp), "cast")
@@ -345,9 +200,17 @@ class FlatAdam(object):
         return b["grad"][o:o + n].view(p.shape)
 
     def accumulate(self, p, g):
-        b = self.slot[p][0]
+        b, o, n = self.slot[p]
         if b["launched"]:
-            raise RuntimeError("gradient for a parameter whose bucket was already reduced (the contribution pattern changed between steps)")
+            # the contribution pattern changed since it was learned: this bucket has left for its all-reduce.  Collect the late-comer in a
+            # side buffer that finish() all-reduces and adds (mean of the early part + mean of the late part = mean of the whole)
+            if b["late"] is None:
+                b["late"] = torch.zeros(b["n"], dtype=torch.float32, device=b["grad"].device)
+            b["late"][o:o + n].view(p.shape).add_(g.view(p.shape))
+            self.count[p] += 1
+            if p.grad is None:
+                p.grad = self.grad_view(p)
+            return
         v = self.grad_view(p)
         if self.count[p] == 0:
             if g.data_ptr() != v.data_ptr():
@@ -357,9 +220,7 @@ class FlatAdam(object):
             v.add_(g.view_as(v))
         self.count[p] += 1
         if self.expected is not None:
-            exp = self.expected.get(p, 0)
-            if exp == 0 or self.count[p] > exp:
-                raise RuntimeError("unexpected gradient contribution (the contribution pattern changed between steps)")
+            exp = self.expected.get(p, 0)                          # (an unexpected or surplus contribution is simply added; finish() re-learns)
             if self.count[p] == exp:
                 b["pending"] -= 1
                 if b["pending"] == 0:
@@ -369,7 +230,11 @@ class FlatAdam(object):
     def _launch(self, b):
         b["launched"] = True
         world = self._world()
-        if world > 1:
+        if world > 1 and self.exchange_dtype == "fp32":
+            b["grad"].mul_(1.0 / world)                            # pre-divide, then sum (distributed.py:56-58)
+            self.launches_last_step += 1
+            b["handle"] = torch.distributed.all_reduce(b["grad"], group=self.group, async_op=True)
+        elif world > 1:
             if b["xchg"] is None:
                 b["xchg"] = torch.empty(b["n"], dtype=torch.bfloat16, device=b["grad"].device)
             _native.check(_native.lib().emdr2_scale_cast_f32_to_bf16(b["grad"].data_ptr(), b["xchg"].data_ptr(), b["n"], 1.0 / world, _native.stream_ptr()),
@@ -379,27 +244,36 @@ class FlatAdam(object):
 
     def finish(self):
         """After loss.backward(): reduce what is left, wait for everything, widen the exchanged gradients back to fp32."""
-        first = self.expected is None
-        if first:
+        if self.expected is None or any(self.count[p] != self.expected.get(p, 0) for p in self.params):
+            if self.expected is not None:
+                self.pattern_changes += 1                          # (every rank runs the same model code: they all see the change in the same step)
             self.expected = dict(self.count)
-            never = [p for p in self.params if self.count[p] == 0]
-            for p in never:                                        # stays zero forever: nobody writes it
+            idle = [p for p in self.params if self.count[p] == 0]
+            for p in idle:                                         # no gradient this step: zero its slice (a previous step may have written it)
                 self.grad_view(p).zero_()
-            self.inactive = never
-        elif any(self.count[p] != self.expected.get(p, 0) for p in self.params):
-            raise RuntimeError("gradient contributions differ from the first step")
+            self.inactive = idle                                   # ... and leave it untouched by the update, like `grad is None` in apex / torch
         for b in self.buckets:
             if not b["launched"] and any(self.count[p] for p in b["params"]):
                 self._launch(b)
+        world = self._world()
         for b in self.buckets:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
-                _native.check(_native.lib().emdr2_widen_bf16_to_f32(b["xchg"].data_ptr(), b["grad"].data_ptr(), b["n"], _native.stream_ptr()), "widen")
-                self.launches_last_step += 1
+                if self.exchange_dtype == "bf16":
+                    _native.check(_native.lib().emdr2_widen_bf16_to_f32(b["xchg"].data_ptr(), b["grad"].data_ptr(), b["n"], _native.stream_ptr()), "widen")
+                    self.launches_last_step += 1
+            if b["late"] is not None:                              # contributions that missed their bucket's all-reduce (pattern change)
+                if world > 1:
+                    b["late"].mul_(1.0 / world)
+                    torch.distributed.all_reduce(b["late"], group=self.group)
+                b["grad"].add_(b["late"])
+                b["late"] = None
 
     # ---- the update ---------------------------------------------------------------------------------------------------------------------
     def step(self, lr=None):
+        if not self.on_device:
+            raise _native.NativeError("the optimizer step runs on HIP kernels only (no host implementation)")
         lib, sp = _native.lib(), _native.stream_ptr()
         lr = self.lr if lr is None else lr
         if self.expected is None:

@@ -179,7 +179,7 @@ int emdr2_lse_combine(const float *part_max, const float *part_sum, const float 
 
 /* Retriever prior over the K retrieved passages (emdr2_model.py:134-145): logp[b, k] = log_softmax_k( <q[b], c[b, k]> * scale ), scale =
  * 1/sqrt(H) with --retriever-score-scaling; q bf16 [batch, H], c bf16 [batch, K, H], logp / prob (= exp(logp), kept for the backward) fp32
- * [batch, K]; K <= 128.  bwd: bf16 gradients dq [batch, H], dc [batch, K, H] (either may be NULL: --no-query/context-embedder-training). */
+ * [batch, K]; K <= 1024 (-4 above).  bwd: bf16 gradients dq [batch, H], dc [batch, K, H] (either may be NULL: --no-query/context-embedder-training). */
 int emdr2_retriever_prior_fwd(const void *q, const void *c, float *logp, float *prob, int batch, int K, int H, float scale, void *stream);
 int emdr2_retriever_prior_bwd(const float *dlogp, const float *prob, const void *q, const void *c, void *dq, void *dc, int batch, int K, int H,
                               float scale, void *stream);

@@ -54,7 +54,7 @@ def _model_and_inputs():
 
 def _decode(m, qb, incremental):
     from emdr2_amd.model.search_strategy import SampleOrGreedySearch
-    s = SampleOrGreedySearch(L, BOS, EOS, sample=False, topk_evidence=KK, incremental=incremental)
+    s = SampleOrGreedySearch(L, BOS, EOS, sample=False, topk_evidence=KK, incremental=incremental, keep_logits=True)
     uid = -torch.arange(1, B + 1).cuda()
     qlen = (qb != 0).sum(1).cuda()
     outs = s.generate_output(m, uid, qb.cuda(), torch.zeros_like(qb).cuda(), None, qb.cuda(), qlen)

@@ -117,3 +117,33 @@ def test_two_rank_data_parallel_training_over_rccl(tmp_path):
     p0, p1 = torch.load(os.path.join(str(tmp_path), "p0.pt")), torch.load(os.path.join(str(tmp_path), "p1.pt"))
     for a, b in zip(p0, p1):
         assert torch.equal(a, b)
+
+
+def test_bench_two_ranks_on_the_shared_device_prints_both_halves():
+    """The driver's multi-GPU command, dry: `bench.py --gpus 2` under torch.distributed.run as 2 gloo ranks sharing cuda:0 (EMDR2_SINGLE_DEVICE) at a
+    reduced size.  Everything an RCCL run executes runs here except the transport: process-group bring-up through dist_util (the backend is
+    one string), row-sharded scan + ONE all-gather + merge, data-parallel EMDR2 step with the bf16 bucket exchange, the JSON contract."""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "2000000", "--e2e-steps", "1", "--e2e-warmup", "1",
+           "--batch", "4", "--layers", "2", "--keep-last-layers", "0", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines                                      # ONE JSON line, from rank 0
+    r = json.loads(lines[0])
+    assert r["metric"] == "mips_queries_per_sec" and r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
+    assert r["config"]["rows_per_rank"] == [1000000, 1000000] and r["config"]["unproven_queries"] == 0
+    assert r["config"]["allgather_bytes_per_rank"] == 3 * 512 * 50 * 8 and r["config"]["allgather_plus_merge_ms"] > 0
+    assert r["roofline"]["frac"] > 0
+    e = r["e2e"]
+    assert "error" not in e, e
+    assert e["n_gpus"] == 2 and e["steps_per_s"] > 0 and e["config"]["global_batch"] == 8 and e["config"]["packed_sequences"]
+    cs = e["config"]["replica_parameter_checksums"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs                          # the two replicas hold bit-identical parameters after the steps
+    assert e["roofline"]["per_step"]["gemm_nt"]["launches"] > 0

@@ -148,7 +148,7 @@ def test_emdr2_forward_loss_and_gradients_vs_oracle():
 
 
 def test_adam_step_matches_torch_adamw_with_clipping():
-    from emdr2_amd.training import FusedAdam
+    from tests.per_param_adam import FusedAdam
     g = torch.Generator(device="cuda").manual_seed(3)
     ps = [torch.nn.Parameter(torch.randn(s, generator=g, device="cuda")) for s in ((300, 70), (513,), (64, 64))]
     ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
@@ -311,48 +311,6 @@ def test_kl_div_retriever_loss_variant_vs_oracle():
     assert _rel(tl.grad.cpu(), tl_r.grad) < 1e-3
 
 
-def test_gradient_buckets_do_not_change_single_process_training():
-    """GradientBuckets installed (as on a data-parallel run) with world size 1: gradients land in the flat buckets as views (tied
-    embedding: three contributions summed in place), equal to the plain path's, and Adam steps from them."""
-    from emdr2_amd.model import kernels as K
-    from emdr2_amd.model.transformer import Config, T5Model
-    from emdr2_amd.training import FusedAdam, GradientBuckets, get_params_for_weight_decay_optimization
-    rng = np.random.default_rng(9)
-    enc_ids, dec_ids = _ids(rng, (8, 64), 512).cuda(), _ids(rng, (8, 32), 512).cuda()
-    grads = []
-    for use_sink in (False, True):
-        torch.manual_seed(0)
-        K.DROPOUT._sites = 0
-        cfg = Config(num_layers=2, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05)
-        m = T5Model(cfg, 512, checkpoint_activations=True).train()
-        opt = FusedAdam(get_params_for_weight_decay_optimization(m), lr=1e-3)
-        sink = GradientBuckets(m.parameters(), bucket_bytes=1 << 20) if use_sink else None
-        K.GRAD_SINK = sink
-        try:
-            for step in range(2):
-                opt.zero_grad()
-                if sink is not None:
-                    sink.begin_step()
-                logits, _ = m(enc_ids, dec_ids)
-                logits.float().square().mean().backward()
-                if sink is not None:
-                    sink.finish()
-                    w = m.language_model.embedding.word_embeddings.weight          # tied: encoder + decoder embedding + LM head
-                    assert sink.expected[w] == 3 and w.grad.data_ptr() == sink.view[w].data_ptr()
-                    if step == 1:
-                        assert sink.launched_early == len(sink.buckets)             # every bucket closed from inside the backward
-                if step == 0:
-                    grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-                before = m.lm_head.bias.detach().clone()
-                opt.step()
-                assert not torch.equal(before, m.lm_head.bias)
-        finally:
-            K.GRAD_SINK = None
-    assert set(grads[0]) == set(grads[1])
-    for k in grads[0]:
-        assert _rel(grads[1][k], grads[0][k]) < 1e-3, k                  # fp32 atomics reorder sums between runs
-
-
 @pytest.mark.parametrize("clip", [0.0, 1.0])
 def test_flat_adam_matches_per_parameter_adam_on_the_same_gradients(clip):
     """training.FlatAdam (flat buckets: one sum-of-squares + one Adam launch per bucket, decay split inside the bucket) against the
@@ -361,7 +319,8 @@ def test_flat_adam_matches_per_parameter_adam_on_the_same_gradients(clip):
     equal to fp32 round-off after three steps, parameters without a gradient untouched."""
     from emdr2_amd.model import kernels as K
     from emdr2_amd.model.transformer import Config, T5Model
-    from emdr2_amd.training import FlatAdam, FusedAdam, get_params_for_weight_decay_optimization
+    from emdr2_amd.training import FlatAdam, get_params_for_weight_decay_optimization
+    from tests.per_param_adam import FusedAdam
     results = []
     for flat in (False, True):
         torch.manual_seed(0)

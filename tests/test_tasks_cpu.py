@@ -132,6 +132,14 @@ def test_checkpoint_files_carry_version_and_release_checkpoints_restart_the_run(
     torch.save(raw, ck.get_checkpoint_name(d, 0, release=True))
     with pytest.raises(ValueError):
         ck.load_checkpoint(d, object())
+    # ... but only on the resume path: the pretrained-model loaders read a file without the key as version 1.0, like the reference's
+    # (checkpointing.py:267-340 never consult the version) -- ADVICE r2
+    seen = {}
+    monkeypatch.setattr(ck, "load_t5_state_dict", lambda model, sd: seen.setdefault("t5", sd))
+    monkeypatch.setattr(ck, "load_dualencoder_state_dict", lambda model, sd, **kw: seen.setdefault("de", sd))
+    ck.load_t5_checkpoint(object(), d)
+    ck.load_dualencoder_checkpoint(object(), d)
+    assert "t5" in seen and "de" in seen
     # a reference-format optimizer state gives a pointer to --no-load-optim instead of a KeyError
     class BadOpt(Opt):
         def load_state_dict(self, sd): raise KeyError("step")
