@@ -66,9 +66,12 @@ __device__ __forceinline__ float half_sum(float x)
 template <bool DROP, bool CAUSAL>
 __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
 {
-    // LDS: 2 stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h)
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
-    __shared__ unsigned long long kmask_s[1024];   // key-padding bits, one word per 64-key block (sk <= 65536)
+    // LDS (dynamic): 3 stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h), then the
+    // key-padding bits, one 64-bit word per 64-key block.  Three stages = TWO blocks of DMA in flight while one is consumed: a packed
+    // sequence of ~140 tokens is 3 blocks in all, and with a one-block look-ahead every block paid a full memory latency (the softmax of a
+    // block takes ~0.5 us, the fetch of the next one 1 - 2 us).  48 KiB + the mask words keeps three workgroups on a CU.
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *kmask_s = (unsigned long long *)(smem + 3 * 16384);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -88,13 +91,6 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const int qc = qvalid ? qi : sq - 1;
     const bool wave_live = q0 < sq;                 // a wave past the end of its sequence only helps to stage K / V (decoder: sq = 32 of 128)
 
-    // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
-    const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
-    bf16x8 qf[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) qf[t] = *(const bf16x8 *)(qrow + (16 * t + 8 * hi) * 2);
-    const bool qpad = !qvalid || p.ids_q[qrow0 + qc] == 0;
-
     // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves pieces w, w + NW, .. of each: 8 rows x 128 B,
     // lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row) (tile_swz has period 8 in the row)
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
@@ -111,6 +107,18 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
         }
     };
+    // the first two K / V blocks go out before anything else touches global memory: short (packed) sequences have only 2 - 4 blocks per
+    // workgroup, and a prologue that first waits for its Q rows and key ids and only then starts the DMA pays the memory latency twice
+    issue(0, 0);
+    if (nblk > 1) issue(1, 1);
+
+    // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
+    const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) qf[t] = *(const bf16x8 *)(qrow + (16 * t + 8 * hi) * 2);
+    const bool qpad = !qvalid || p.ids_q[qrow0 + qc] == 0;
+
     uint32_t vtr[2][2], kra[4];
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
     row_frag_addresses((uint32_t)(uintptr_t)smem, lane, kra);
@@ -135,12 +143,21 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
     const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)(stat0 + qc));
 
-    issue(0, 0);
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int stage = blk & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // this block's tiles (the only DMA in flight)
-        __syncthreads();                                                          // ... from every wave; everyone is done with the other stage
-        if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);
+    // everything the prologue fetched is complete HERE, stated in a form the compiler sees (the asm "defines" the Q fragments): left to
+    // itself it would put the wait for the Q rows at their first use inside the loop, as vmcnt(0) -- and drain the look-ahead DMA with it
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
+    int stage = 0;
+    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
+        // this block's tiles have landed once at most the NEXT block's pieces (2 x 8 / NW DMA instructions of this wave, issued later and
+        // retired in order) are still in flight; everything older -- Q rows, key ids -- has long returned
+        if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / NW)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // raw barrier: __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0) -- it would wait for the look-ahead DMA as well.
+        // What must be ordered here is LDS only: the mask words of the prologue and (through each wave's own counted wait above) the tiles.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                             // every wave's pieces have landed; everyone is done with the block before
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 2 < nblk) issue(blk + 2, stage == 0 ? 2 : stage - 1);           // into the stage the previous block has just left
         if (!wave_live) continue;
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * KB;
@@ -312,12 +329,13 @@ static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
-    dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads));
+    dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads, heads));
+    const size_t lds = 3 * 16384 + (size_t)((sk + KB - 1) / KB) * 8;            // <= 56 KiB (sk <= 65536): under the 64 KiB a kernel gets without opting in
     OpsTimer timer(OPS_ATTN_FWD, 4.0 * heads * pairs * 64, (hipStream_t)stream);
-    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-    else if (causal) hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(NW * 64), 0, (hipStream_t)stream, p);
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 

@@ -82,8 +82,9 @@ __device__ __forceinline__ SeqExtent seq_extent(const BwdParams &p, int b, int n
 template <bool DROP, bool CAUSAL>
 __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams p)
 {
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];       // 2 stages x (K tile 8 KiB + V tile 8 KiB)
-    __shared__ unsigned long long kmask_s[1024];
+    // dynamic LDS: 3 stages x (K tile 8 KiB + V tile 8 KiB) + one key-mask word per 64-key block; two blocks of DMA in flight (attention.hip)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    unsigned long long *kmask_s = (unsigned long long *)(smem + 3 * 16384);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -97,6 +98,23 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const bool qvalid = qi < sq;
     const int qc = qvalid ? qi : sq - 1;
     const bool wave_live = q0 < sq;
+
+    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
+    const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2 + pslot * 16;
+    const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
+    const int nblk = (sk + 63) / 64;
+    auto issue = [&](int blk, int stage) {
+        char *sb = smem + stage * 16384;
+#pragma unroll
+        for (int i = 0; i < 8 / BNW; ++i) {
+            long long key = blk * 64 + prow + 8 * BNW * i;
+            if (key >= sk) key = sk - 1;                                           // keys past sk: re-read the last row, masked below
+            __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
+        }
+    };
+    issue(0, 0);                     // before the fragment / statistics loads below: a short sequence must not pay the memory latency twice
+    if (nblk > 1) issue(1, 1);
 
     bf16x8 qf[4], dof[4];
     load_row_frags(p.q + (ex.q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2, hi, qf);
@@ -125,20 +143,6 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const float sc = p.scale * L2E;
     const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
 
-    const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
-    const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2 + pslot * 16;
-    const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = (sk + 63) / 64;
-    auto issue = [&](int blk, int stage) {
-        char *sb = smem + stage * 16384;
-#pragma unroll
-        for (int i = 0; i < 8 / BNW; ++i) {
-            long long key = blk * 64 + prow + 8 * BNW * i;
-            if (key >= sk) key = sk - 1;                                           // keys past sk: re-read the last row, masked below
-            __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + key * p.k_ss * 2), (lptr_t *)(sb + (wave + BNW * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
-        }
-    };
     for (int blk = wave; blk < nblk; blk += BNW) {
         const int key = blk * 64 + lane;
         const unsigned long long w = __builtin_amdgcn_ballot_w64(key < sk && p.ids_k[ex.krow0 + (key < sk ? key : sk - 1)] != 0);
@@ -157,12 +161,14 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
     const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)si);
 
-    issue(0, 0);
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int stage = blk & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);
+    int stage = 0;
+    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
+        if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / BNW)) : "memory");      // all but the next block's pieces
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // raw barrier (no fence: the look-ahead DMA stays in flight)
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        if (blk + 2 < nblk) issue(blk + 2, stage == 0 ? 2 : stage - 1);
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * 64;
         // every (query of this wave, key of this block) pair masked -> dS == 0: nothing to add
@@ -267,12 +273,6 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const bool kvalid = key < sk;                                       // (dense: sk % 32 == 0, so a live wave's keys are all valid)
     const int kc = kvalid ? key : sk - 1;
 
-    bf16x8 kf[4], vf[4];
-    load_row_frags(p.k + (ex.k_off + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
-    load_row_frags(p.v + (ex.v_off + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
-    const bool kpad = !kvalid || p.ids_k[ex.krow0 + kc] == 0;
-    const float sc = p.scale * L2E;
-
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *q_src = p.q + (ex.q_off + (long long)n * p.q_sn) * 2 + pslot * 16;
     const char *o_src = p.dout + (ex.qrow0 * p.heads + n) * 128 + pslot * 16;
@@ -287,6 +287,14 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
             __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + KNW * i) * 1024), 16, 0, 0);
         }
     };
+    issue(0, 0);                     // first Q / dO block in flight before this wave's K / V rows and the statistics are fetched
+
+    bf16x8 kf[4], vf[4];
+    load_row_frags(p.k + (ex.k_off + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
+    load_row_frags(p.v + (ex.v_off + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
+    const bool kpad = !kvalid || p.ids_k[ex.krow0 + kc] == 0;
+    const float sc = p.scale * L2E;
+
     // per-query statistics of a block, loaded by wave 0 one block ahead into registers and written to LDS a block later, so the
     // global-load latency never sits between a barrier and the tiles' DMA
     float nx_pm = 0.f, nx_d = 0.f;
@@ -321,7 +329,6 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const bool codd = kc & 1;
 
     if (wave == 0) { load_stats(0); store_stats(0); if (nblk > 1) load_stats(1); }
-    issue(0, 0);
     for (int blk = 0; blk < nblk; ++blk) {
         const int stage = blk & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -469,12 +476,13 @@ static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
     OpsTimer timer(OPS_ATTN_BWD, 10.0 * heads * pairs * 64, (hipStream_t)stream);
-    const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads));
-    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else if (causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL((attention_bwd_dq_kernel<false, false>), dq_grid, dim3(BNW * 64), 0, (hipStream_t)stream, p);
-    const dim3 kv_grid(attn_grid((sk + KNW * 32 - 1) / (KNW * 32), batch * heads));
+    const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads, heads));
+    const size_t dq_lds = 3 * 16384 + (size_t)((sk + 63) / 64) * 8;
+    if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, true>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
+    else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
+    else if (causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attention_bwd_dq_kernel<false, false>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
+    const dim3 kv_grid(attn_grid((sk + KNW * 32 - 1) / (KNW * 32), batch * heads, heads));
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, false>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     else if (causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<false, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);

@@ -116,15 +116,30 @@ __device__ __forceinline__ void tr_addresses(uint32_t tile_lds, int lane, uint32
 
 // 1-D grid decode shared by the attention kernels: workgroup ids go round-robin to the 8 XCDs (one L2 each); the blocks of one (batch,
 // head) -- which stream the same K/V (or Q/dO) rows -- are given ids 8 apart so they land on the SAME XCD and the shared operand leaves HBM
-// once.  ids: xcd = id & 7, rest = id >> 3, block = rest % nblk, bn = (rest / nblk) * 8 + xcd; returns false for the padded tail.
+// once.  With >= 64 sequences the HEADS of a sequence stay on one XCD as well (sequence b -> XCD b % 8, its heads and blocks consecutive
+// there): a token's q / k / v for all heads are one contiguous row of the packed projection output, and short (packed) sequences are
+// memory-bound -- 70 flop per byte at 140 tokens -- so it matters that the 128-byte head slices of a row are fetched by one L2 close
+// together in time instead of by eight L2s at eight different moments.  Returns false for the padded tail.
 __device__ __forceinline__ bool attn_decode(int id, int nblk, int total_bn, int heads, int &blk, int &b, int &n)
 {
     const int xcd = id & 7, rest = id >> 3;
     blk = rest % nblk;
-    const int bn = (rest / nblk) * 8 + xcd;
+    const int r2 = rest / nblk;
+    const int batch = total_bn / heads;
+    if (batch >= 64) {
+        n = r2 % heads;
+        b = (r2 / heads) * 8 + xcd;
+        return b < batch;
+    }
+    const int bn = r2 * 8 + xcd;
     if (bn >= total_bn) return false;
     b = bn / heads; n = bn - b * heads;
     return true;
 }
-__host__ __forceinline__ unsigned attn_grid(int nblk, int total_bn) { return (unsigned)(((total_bn + 7) / 8) * 8 * nblk); }
+__host__ __forceinline__ unsigned attn_grid(int nblk, int total_bn, int heads)
+{
+    const int batch = total_bn / heads;
+    if (batch >= 64) return (unsigned)(((batch + 7) / 8) * 8 * heads * nblk);
+    return (unsigned)(((total_bn + 7) / 8) * 8 * nblk);
+}
 #endif

@@ -19,11 +19,12 @@ namespace {
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -3)
 
 // One workgroup: len[i] by a wave per sequence (ballot over 64-token chunks), then an exclusive scan of the lengths by the whole group.
-// Also emits sum(len^2) (the attention score count of the packed self-attention, for flop accounting) next to the total.
+// Also emits sum(len^2) (the attention score count of the packed self-attention, for flop accounting) and the longest length (the attention
+// grids are sized by it) next to the total.
 __global__ void __launch_bounds__(1024) seq_lengths_kernel(const long long *ids, int n, int S, int *cu, long long *totals)
 {
     extern __shared__ int len_s[];               // n ints
-    __shared__ int part[16];
+    __shared__ int part[16], max_part[16];
     __shared__ long long sq_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int i = wave; i < n; i += 16) {
@@ -38,16 +39,16 @@ __global__ void __launch_bounds__(1024) seq_lengths_kernel(const long long *ids,
     __syncthreads();
     // scan: thread t owns a contiguous chunk of sequences
     const int per = (n + 1023) / 1024, lo = tid * per, hi = min(n, lo + per);
-    int sum = 0;
+    int sum = 0, mx = 0;
     long long sq = 0;
-    for (int i = lo; i < hi; ++i) { sum += len_s[i]; sq += (long long)len_s[i] * len_s[i]; }
+    for (int i = lo; i < hi; ++i) { sum += len_s[i]; sq += (long long)len_s[i] * len_s[i]; mx = max(mx, len_s[i]); }
     int incl = sum;
 #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) sq += __shfl_xor(sq, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) { sq += __shfl_xor(sq, d, 64); mx = max(mx, __shfl_xor(mx, d, 64)); }
     if (lane == 63) part[wave] = incl;
-    if (lane == 0) sq_part[wave] = sq;
+    if (lane == 0) { sq_part[wave] = sq; max_part[wave] = mx; }
     __syncthreads();
     int base = incl - sum;
     for (int w = 0; w < wave; ++w) base += part[w];
@@ -55,8 +56,9 @@ __global__ void __launch_bounds__(1024) seq_lengths_kernel(const long long *ids,
     if (tid == 1023) {
         cu[n] = base;
         long long tot = 0;
-        for (int w = 0; w < 16; ++w) tot += sq_part[w];
-        totals[0] = base; totals[1] = tot;
+        int longest = 0;
+        for (int w = 0; w < 16; ++w) { tot += sq_part[w]; longest = max(longest, max_part[w]); }
+        totals[0] = base; totals[1] = tot; totals[2] = longest;
     }
 }
 

@@ -213,9 +213,9 @@ class PackedSeqs(object):
         self.n, self.S, self.max_len, self.group = n, S, S, 1
         self.dense_ids = ids                                  # the [n, S] grid this layout was built from (consumers that want the reference's shapes)
         self.cu = torch.empty(n + 1, dtype=torch.int32, device=dev)
-        totals = torch.empty(2, dtype=torch.int64, device=dev)
+        totals = torch.empty(3, dtype=torch.int64, device=dev)
         _native.check(lib.emdr2_seq_lengths(ids.data_ptr(), n, S, self.cu.data_ptr(), totals.data_ptr(), _sp()), "seq_lengths")
-        self.total, self.pairs = (int(v) for v in totals.tolist())                  # the layout's one host sync
+        self.total, self.pairs, self.max_len = (int(v) for v in totals.tolist())    # the layout's one host sync (max_len sizes the attention grids)
         PACKING.real_tokens += self.total
         PACKING.grid_tokens += n * S
         # rows: whole GEMM tiles; for large stacks a coarser granule (<= 1.6 % more rows) so that the activation sizes of successive training
@@ -238,7 +238,7 @@ class PackedSeqs(object):
             raise ValueError("grouping needs an ungrouped layout of a multiple of k sequences")
         g = object.__new__(PackedSeqs)
         g.__dict__.update(self.__dict__)
-        g.n, g.max_len, g.group = self.n // k, self.S * k, k
+        g.n, g.max_len, g.group = self.n // k, min(self.S, self.max_len) * k, k
         g.cu = self.cu[::k].contiguous()
         g.pairs = None
         return g

@@ -45,7 +45,7 @@ def test_layout_matches_numpy(n, S):
     types = rng.integers(0, 2, size=(n, S)).astype(np.int64)
     seqs = K.PackedSeqs(torch.from_numpy(ids).cuda(), torch.from_numpy(types).cuda())
     cu = np.concatenate([[0], np.cumsum(lens)])
-    assert seqs.total == int(cu[-1]) and seqs.pairs == int((lens.astype(np.int64) ** 2).sum())
+    assert seqs.total == int(cu[-1]) and seqs.pairs == int((lens.astype(np.int64) ** 2).sum()) and seqs.max_len == int(lens.max())
     assert seqs.rows % K.PackedSeqs.ROW_MULTIPLE == 0 and 0 <= seqs.rows - seqs.total < (K.PackedSeqs.ROW_MULTIPLE if seqs.total < 65536 else 16384)
     assert np.array_equal(seqs.cu.cpu().numpy(), cu)
     rowmap = np.full(seqs.rows, -1, dtype=np.int64)
@@ -63,7 +63,7 @@ def test_layout_matches_numpy(n, S):
     assert g is seqs
     if n % 5 == 0:
         g5 = seqs.grouped(5)
-        assert g5.n == n // 5 and g5.max_len == 5 * S and np.array_equal(g5.cu.cpu().numpy(), cu[::5])
+        assert g5.n == n // 5 and g5.max_len == 5 * int(lens.max()) and np.array_equal(g5.cu.cpu().numpy(), cu[::5])
 
 
 def test_pack_unpack_first_rows_and_their_gradients():
