@@ -52,6 +52,9 @@ def add_args(ap):
     ap.add_argument("--keep-last-layers", default="auto",
                     help="reader-encoder layers whose activations are kept instead of re-run in the backward: a number, or 'auto' = as many as "
                          "fit the HBM left over after a first full-recompute step with 25 GB to spare (falls back to 0 on an allocation failure)")
+    ap.add_argument("--selective-layers", default="auto",
+                    help="encoder layers run with selective activation retention (6 of ~16 [tokens, h] tensors kept, FFN intermediates rebuilt in "
+                         "the backward): 'auto' = reader encoder first, then the context tower, as HBM allows; or 'R,C' (reader, context tower)")
     ap.add_argument("--no-packing", action="store_true",
                     help="run the encoder stacks over the reference's padded [batch, S] grids instead of the packed real tokens (A/B)")
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
@@ -136,32 +139,49 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(keep_last_arg=getattr(args, "keep_last_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
-def choose_keep_last(ctx, world):
-    """How many of the last reader-encoder layers keep their activations (transformer.ParallelTransformer.keep_last).  'auto': from the peak
-    of the full-recompute warm-up step.  The first kept layer is free (it replaces the transient of the layer re-run that set the peak), every
-    further one is budgeted at 18 bf16 [tokens, H] tensors (16.3 measured); 25 GB are left to spare.  All ranks take the minimum."""
-    want = getattr(ctx, "keep_last_arg", "auto")
-    if want != "auto":
-        return max(0, min(int(want), ctx.layers))
+def choose_retention(ctx, world):
+    """How the HBM left over after a full-recompute step is spent on NOT recomputing (all ranks take the minimum):
+      selective retention (transformer.ParallelTransformerLayer.forward_selective): +4 [tokens, h] tensors per layer over a checkpointed
+        layer, saves 2/3 of that layer's re-run -- reader encoder first (the largest stack), then the context tower;
+      keep_last: what is still free upgrades the LAST reader-encoder layers to keeping everything (+10 more tensors, saves the last third).
+    Returns (keep_last, selective_reader, selective_context)."""
+    from emdr2_amd.model import kernels as Kmod
+    L = ctx.layers
+    want_keep, want_sel = getattr(ctx, "keep_last_arg", "auto"), getattr(ctx, "selective_arg", "auto")
     free, total = torch.cuda.mem_get_info()
     capacity = free + torch.cuda.memory_reserved()            # what this process can have: its own pool + what is still free
-    peak = torch.cuda.max_memory_reserved()
-    # measured: 41 GB per kept layer at B = 64, K = 50, S = 512 padded (16.3 tensors of [tokens, H] bf16); packed: the real-token share of it
-    from emdr2_amd.model import kernels as Kmod
-    share = (Kmod.PACKING.real_tokens / Kmod.PACKING.grid_tokens) if (Kmod.PACKING.enabled and Kmod.PACKING.grid_tokens) else 1.0
-    per_layer = int(ctx.B * ctx.K * ctx.S * H * 2 * 18 * min(1.0, share * 1.15))
-    spare = (25 << 30) if not Kmod.PACKING.enabled else (40 << 30)     # packed: the token count (and so every activation size) moves from step to step
-    n = int(1 + (capacity - spare - peak) // per_layer) if capacity - spare > peak else 0
-    n = max(0, min(n, ctx.layers))
+    # what the full-recompute step needed, plus the caching allocator's overhead (measured: reserved = 1.08 x allocated at the peak), plus a
+    # margin: packed token counts -- and with them every activation size -- move by a fraction of a percent from step to step
+    peak = int(torch.cuda.max_memory_allocated() * 1.08)
+    spare = (25 << 30) if not Kmod.PACKING.enabled else (28 << 30)
+    budget = max(0, int((capacity - spare - peak) / 1.08))
+    hist = [(S, rows) for n, S, rows in Kmod.PACKING.history if n == ctx.B * ctx.K] if Kmod.PACKING.enabled else []
+    rows_reader = max([r for S, r in hist if S == ctx.S] + [0]) or ctx.B * ctx.K * ctx.S                 # (the larger of the two S-long stacks: qext)
+    rows_ctx = max([r for S, r in hist if S == ctx.S_ret] + [0]) or ctx.B * ctx.K * ctx.S_ret
+    unit_r, unit_c = rows_reader * H * 2, rows_ctx * H * 2                                                 # one [tokens, h] bf16 tensor
+    if want_sel != "auto":
+        sel_r, sel_c = (int(v) for v in str(want_sel).split(","))
+    else:
+        # measured at B = 64, K = 50: 6.3 GB per selective reader-encoder layer (3.2 tensors of [1.29M, 768] bf16 over a checkpointed one),
+        # 3.0 GB per context-tower layer (4.4 tensors of [0.44M, 768]); a fully kept layer 14.5 GB (7.3 tensors): budgeted at 3.6 / 4.8 / 8.0
+        sel_r = int(min(L, budget // (3.6 * unit_r)))
+        budget -= sel_r * 3.6 * unit_r
+        sel_c = int(min(L, budget // (4.8 * unit_c))) if sel_r == L else 0
+        budget -= sel_c * 4.8 * unit_c
+    if want_keep != "auto":
+        keep = max(0, min(int(want_keep), L))
+    else:
+        keep = int(min(sel_r, budget // (8.0 * unit_r)))      # a kept layer replaces a selective one
+    sel_r = min(sel_r, L - keep)
     if world > 1:
-        t = torch.tensor([n], device="cuda")
+        t = torch.tensor([keep, sel_r, sel_c], device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MIN)
-        n = int(t.item())
-    return n
+        keep, sel_r, sel_c = (int(v) for v in t.tolist())
+    return keep, sel_r, sel_c
 
 
 def run(ctx, steps, warmup, world):
@@ -177,32 +197,40 @@ def run(ctx, steps, warmup, world):
         torch.cuda.synchronize()
 
     loss = None
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()                     # (the corpus / index builders of setup() peak higher than a training step)
     for _ in range(warmup):
         loss = ctx.step()
     fence()
-    keep = choose_keep_last(ctx, world)
+    keep, sel_r, sel_c = choose_retention(ctx, world)
     full_ms = None
-    if keep > 0:
+    if keep + sel_r + sel_c > 0:
         t0 = time.perf_counter()                             # for the record: one step with the reference's full per-layer recompute
         loss = ctx.step()
         fence()
         full_ms = (time.perf_counter() - t0) * 1e3
         warmup += 1
-        # then one more untimed step so the allocator has grown before the timed region
-        ctx.model.set_recompute_keep_last(keep)
-        try:
-            loss = ctx.step()
-            warmup += 1
-        except torch.cuda.OutOfMemoryError:                  # the estimate was too optimistic on this box: back to full recompute
-            keep = 0
-            ctx.model.set_recompute_keep_last(0)
-            ctx.opt.zero_grad()
-            torch.cuda.empty_cache()
+        # then one more untimed step so the allocator has grown before the timed region; if the estimate was too optimistic on this box the
+        # plan is thinned out (context tower first, then half of the reader layers, then the reference's full recompute)
+        for plan in ((keep, sel_r, sel_c), (0, sel_r, 0), (0, sel_r // 2, 0), (0, 0, 0)):
+            keep, sel_r, sel_c = plan
+            ctx.model.set_recompute_keep_last(keep)
+            ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
+            torch.cuda.empty_cache()                         # blocks cached for the previous retention pattern do not fit the new one
+            try:
+                loss = ctx.step()
+                warmup += 1
+                break
+            except torch.cuda.OutOfMemoryError:
+                ctx.opt.zero_grad()
+                import gc
+                gc.collect()
         fence()
-    ctx.keep_last, ctx.full_recompute_ms = keep, (full_ms if keep > 0 else None)
+    ctx.keep_last, ctx.selective, ctx.full_recompute_ms = keep, (sel_r, sel_c), (full_ms if keep + sel_r + sel_c > 0 else None)
     lib.emdr2_ops_set_timing(1)
     from emdr2_amd.model import kernels as Kmod
     Kmod.PACKING.real_tokens = Kmod.PACKING.grid_tokens = 0
+    Kmod.RECOMPUTE.flops = 0.0
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = ctx.step()
@@ -237,7 +265,10 @@ def run(ctx, steps, warmup, world):
                    "tokens_real": (Kmod.PACKING.real_tokens // steps) if Kmod.PACKING.enabled else None,
                    "tokens_padded": (Kmod.PACKING.grid_tokens // steps) if Kmod.PACKING.enabled else
                                     ctx.B * ctx.S_ret + ctx.B * ctx.K * ctx.S_ret + 2 * ctx.B * ctx.K * ctx.S,
-                   "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (activations kept in HBM)" % ctx.keep_last if ctx.keep_last else ""),
+                   "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
+                                           ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
+                                            "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),
+                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12,
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()), "replica_parameter_checksums": replicas,
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),

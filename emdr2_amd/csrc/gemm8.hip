@@ -50,6 +50,7 @@ struct G8Params {
     const long long *labels;
     int stagger;               // XCD start stagger: 1/64ths of a 1,024-cycle nap per K-tile and XCD index, 0 = off
     int ablate;                // -DEMDR2_EXPERIMENTS builds only (EMDR2_G8_ABLATE): 1 = no epilogue, 2 = epilogue without global stores
+    int nt_a;                  // A half-tiles with the non-temporal cache policy (an A panel is used by the n-tiles of ONE round of its XCD, then never again)
 };
 
 __device__ __forceinline__ void tile_coords(const G8Params &p, int pos, int &tm, int &tn)
@@ -115,8 +116,13 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
         const uint32_t off_ = ((T) == 0 || (T) == 3) ? offA : offB;                                                                       \
         const long long half_ = ((T) == 0 || (T) == 3) ? 128 * lda2 : 128 * ldb2;                                                         \
         char *dst_ = smem + (SB) * G8_BUF + (T) * G8_SLOT + wave * 1024;                                                                   \
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + off_), (lptr_t *)dst_, 16, 0, 0);                                              \
-        __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + half_ + off_), (lptr_t *)(dst_ + 8192), 16, 0, 0);                             \
+        if (((T) == 0 || (T) == 3) && p.nt_a) {                                                                                           \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + off_), (lptr_t *)dst_, 16, 0, 2);                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + half_ + off_), (lptr_t *)(dst_ + 8192), 16, 0, 2);                         \
+        } else {                                                                                                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + off_), (lptr_t *)dst_, 16, 0, 0);                                          \
+            __builtin_amdgcn_global_load_lds((gptr_t *)(src_ + half_ + off_), (lptr_t *)(dst_ + 8192), 16, 0, 0);                         \
+        }                                                                                                                                 \
         if ((T) == 3) {                                                                                                                   \
             sA += 128; sB += 128;                                                                                                         \
             if (++s_kt == KT) { s_kt = 0; cursor_tile(++s_i); }                                                                           \
@@ -447,6 +453,12 @@ int g8_launch(G8Params &p, hipStream_t stream)
     if (single_env > 0) single_kb = single_env;
 #endif
     if (ng > p.tiles_n || 2 * ng < p.tiles_n || (long long)p.N * p.K * 2 <= (single_kb << 10)) ng = p.tiles_n;
+#ifdef EMDR2_EXPERIMENTS
+    static const int ng_env = getenv("EMDR2_G8_NGROUP") ? atoi(getenv("EMDR2_G8_NGROUP")) : 0;
+    if (ng_env > 0) ng = ng_env < p.tiles_n ? ng_env : p.tiles_n;
+    static const int nt_env = getenv("EMDR2_G8_NT") ? atoi(getenv("EMDR2_G8_NT")) : 0;
+    p.nt_a = nt_env;
+#endif
     const int groups = (p.tiles_n + ng - 1) / ng;
     p.ngroup = (p.tiles_n + groups - 1) / groups;
     auto magic = [](long long d) { return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d); };

@@ -262,6 +262,14 @@ class EMDR2Model(torch.nn.Module):
         (tests/test_model_gpu.py); ~33 GB of HBM per layer at B = 64, K = 50, S = 512."""
         self.language_model.language_model.encoder.keep_last = max(0, int(reader_encoder_layers))
 
+    def set_selective_retention(self, reader_encoder_layers, context_tower_layers=0, query_tower_layers=0):
+        """Under --checkpoint-activations, run the last n layers of an encoder stack with SELECTIVE retention (6 [tokens, h] tensors kept per
+        layer, LayerNorm outputs and the FFN intermediates rebuilt in the backward by one h -> 4h GEMM) instead of re-running the whole
+        layer: ~8 GB per reader-encoder layer at the benchmark shape for two thirds of that layer's recompute.  Gradients unchanged."""
+        self.language_model.language_model.encoder.selective = max(0, int(reader_encoder_layers))
+        self.retriever_model.context_model.language_model.encoder.selective = max(0, int(context_tower_layers))
+        self.retriever_model.query_model.language_model.encoder.selective = max(0, int(query_tower_layers))
+
     def load_state_dict(self, state_dict, strict=True, **kw):
         """The reference's name for the above (emdr2_model.py:228-231 overrides nn.Module.load_state_dict with the nested form);
         a flat torch state dict still goes to nn.Module."""

@@ -53,8 +53,21 @@ DROPOUT = _DropoutState()
 
 
 # ---- raw kernels --------------------------------------------------------------------------------------------------------
+class _RecomputeMeter(object):
+    """GEMM flops spent RE-running forward work inside a backward: the re-run of a checkpointed layer (ATTN_STASH.mode == 'consume') or the
+    FFN-1 / projection recomputation of the selective-retention functions (`active` > 0).  bench_e2e.py reports it per step."""
+
+    def __init__(self):
+        self.flops, self.active = 0.0, 0
+
+
+RECOMPUTE = _RecomputeMeter()
+
+
 def gemm_nt(A, lda, B, ldb, C, ldc, M, N, K, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None,
             gelu=False, pre_act=None, residual=None, split_k=1, drop_p=0.0, seed=0, residual_mode=0):
+    if RECOMPUTE.active or ATTN_STASH.mode == 'consume':
+        RECOMPUTE.flops += 2.0 * M * N * K * batch1 * batch2
     _native.check(_lib().emdr2_gemm_nt_bf16(A.data_ptr(), lda, B.data_ptr(), ldb, C.data_ptr(), ldc, M, N, K, batch1, sA1, sB1, sC1, batch2, sA2,
                                             sB2, sC2, alpha, _ptr(bias), int(gelu), _ptr(pre_act), _ptr(residual), int(residual_mode),
                                             int(C.dtype == torch.float32), split_k, float(drop_p), int(seed), _sp()), "gemm_nt_bf16")
@@ -187,6 +200,7 @@ class _Packing(object):
     def __init__(self):
         self.enabled = True
         self.real_tokens = self.grid_tokens = 0          # running totals over the layouts built so far (bench: tokens_real / tokens_padded)
+        self.history = []                                # (n, S, rows) of the most recent layouts (bench: activation budget per stack)
 
 
 PACKING = _Packing()
@@ -222,6 +236,7 @@ class PackedSeqs(object):
         # steps -- whose real-token counts differ by a fraction of a percent -- repeat and the caching allocator reuses its blocks
         m = self.ROW_MULTIPLE if self.total < (1 << 16) else (8192 if self.total < (1 << 20) else 16384)
         self.rows = (self.total + m - 1) // m * m
+        PACKING.history = PACKING.history[-15:] + [(n, S, self.rows)]
         self.rowmap = torch.empty(self.rows, dtype=torch.int32, device=dev)         # packed row -> dense row (i * S + pos), -1 in the tail
         self.inverse = torch.empty(n * S, dtype=torch.int32, device=dev)            # dense row -> packed row, -1 at dropped pad rows
         self.ids = torch.empty(self.rows, dtype=torch.int64, device=dev)
@@ -464,6 +479,165 @@ class LayerNormFn(torch.autograd.Function):
         _accum_grad(gamma, dg)
         _accum_grad(beta, db)
         return dx.reshape(dy.shape), None, None, None, None
+
+
+def _ln_forward(x2, gamma, beta, eps):
+    rows, H = x2.shape
+    y = torch.empty_like(x2)
+    mean = torch.empty(rows, dtype=torch.float32, device=x2.device)
+    rstd = torch.empty_like(mean)
+    _native.check(_lib().emdr2_layernorm_fwd(x2.data_ptr(), gamma.data_ptr(), beta.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                             rows, H, eps, _sp()), "layernorm_fwd")
+    return y, mean, rstd
+
+
+def _ln_backward(dy2, x2, gamma, beta, mean, rstd, dres):
+    """dx of LayerNorm (+ dres, the gradient of a residual branch that by-passed it); accumulates the gain / bias gradients."""
+    rows, H = x2.shape
+    dx = torch.empty_like(x2)
+    dg = torch.zeros(H, dtype=torch.float32, device=x2.device)
+    db = torch.zeros_like(dg)
+    _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
+                                             dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
+    _accum_grad(gamma, dg)
+    _accum_grad(beta, db)
+    return dx
+
+
+def _linear_param_grads(dy2, x2, weight, bias, row_perm):
+    """dW = dy^T x (+ bias gradient) of a linear layer, delivered to the parameter (rows permuted back to the checkpoint's order)."""
+    N = weight.shape[0]
+    if dy2.shape[0] % 32:
+        raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
+    db = torch.zeros(N, dtype=torch.float32, device=dy2.device) if bias is not None else None
+    dW = weight_grad_tn(dy2, x2, colsum=db)
+    if row_perm is not None:
+        un = torch.empty_like(dW); un[row_perm] = dW; dW = un
+        if bias is not None:
+            ub = torch.empty_like(db); ub[row_perm] = db; db = ub
+    _accum_grad(weight, dW)
+    if bias is not None:
+        _accum_grad(bias, db)
+
+
+class LNLinearFn(torch.autograd.Function):
+    """(Linear(LayerNorm(x)), x): the pre-LN projection of a transformer block (transformer.py:474-490: input_layernorm ->
+    query_key_value) as ONE node that keeps only x and the row statistics.  The normalised activations -- a [tokens, h] tensor per layer
+    that `LayerNormFn` + `LinearFn` would hold for the weight gradient -- are rebuilt by the (HBM-bound) LayerNorm kernel in the backward.
+    The second output hands the residual stream through, so its gradient is folded into the LayerNorm backward kernel.  Part of the
+    selective activation retention of `ParallelTransformerLayer` (mode 'selective')."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, weight, bias, row_perm):
+        _check_bf16(x)
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            raise ValueError("input must be contiguous")
+        M, N = x2.shape[0], weight.shape[0]
+        ln, mean, rstd = _ln_forward(x2, gamma, beta, eps)
+        y = torch.empty((M, N), dtype=BF16, device=x.device)
+        wb = w_bf16(weight) if row_perm is None else w_bf16_perm(weight, row_perm)
+        bb = None
+        if bias is not None:
+            bb = bias.detach() if row_perm is None else WEIGHTS.get(bias, "perm", lambda: bias.detach()[row_perm].contiguous())
+        gemm_nt(ln, H, wb, H, y, N, M, N, H, bias=bb)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.gamma, ctx.beta, ctx.eps, ctx.weight, ctx.bias, ctx.row_perm, ctx.shp = gamma, beta, eps, weight, bias, row_perm, x.shape
+        return y.reshape(x.shape[:-1] + (N,)), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dpass):
+        x2, mean, rstd = ctx.saved_tensors
+        weight, bias, row_perm = ctx.weight, ctx.bias, ctx.row_perm
+        M, H = x2.shape
+        N = weight.shape[0]
+        dy2 = dy.reshape(M, N)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        ln, _, _ = _ln_forward(x2, ctx.gamma, ctx.beta, ctx.eps)                           # rebuilt, not stored
+        _linear_param_grads(dy2, ln, weight, bias, row_perm)
+        del ln
+        wt = w_bf16_t(weight) if row_perm is None else WEIGHTS.get(weight, "perm_t", lambda: transpose(w_bf16_perm(weight, row_perm)))
+        dln = matmul_nt(dy2, wt)
+        dres = dpass.reshape(M, H).contiguous() if dpass is not None else None
+        dx = _ln_backward(dln, x2, ctx.gamma, ctx.beta, mean, rstd, dres)
+        return dx.reshape(ctx.shp), None, None, None, None, None, None
+
+
+def ln_linear(x, gamma, beta, eps, weight, bias, row_perm=None):
+    return LNLinearFn.apply(x, gamma, beta, eps, weight, bias, row_perm)
+
+
+class LNMLPFn(torch.autograd.Function):
+    """x + dropout(gelu(LayerNorm(x) W1^T + b1) W2^T + b2): post-attention LayerNorm + ParallelMLP + bias-dropout-add (transformer.py:94-108,
+    397-413,545-563) as ONE node that keeps only x and the row statistics.  The three [tokens, h] / [tokens, 4h] tensors a backward needs --
+    normalised input, FFN pre-activation, GELU output: 9 of the ~16 [tokens, h]-sized tensors a layer would keep -- are rebuilt in the
+    backward by the LayerNorm kernel and ONE GEMM (h -> 4h with the bias + GELU (+ pre-activation) epilogue): a third of the layer's forward
+    flops instead of all of them (per-layer recompute) or none (keeping 32 GB per layer at the benchmark shape)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed):
+        _check_bf16(x)
+        H = x.shape[-1]
+        x2 = x.reshape(-1, H)
+        if not x2.is_contiguous():
+            raise ValueError("input must be contiguous")
+        M, F = x2.shape[0], w1.shape[0]
+        ln, mean, rstd = _ln_forward(x2, gamma, beta, eps)
+        inter = torch.empty((M, F), dtype=BF16, device=x.device)
+        gemm_nt(ln, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True)
+        del ln
+        y = torch.empty((M, H), dtype=BF16, device=x.device)
+        gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=x2, drop_p=drop_p, seed=seed)
+        ctx.save_for_backward(x2, mean, rstd)
+        ctx.params, ctx.eps, ctx.shp, ctx.drop_p, ctx.seed = (gamma, beta, w1, b1, w2, b2), eps, x.shape, drop_p, seed
+        return y.reshape(x.shape)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, mean, rstd = ctx.saved_tensors
+        gamma, beta, w1, b1, w2, b2 = ctx.params
+        M, H = x2.shape
+        F = w1.shape[0]
+        if M % 32:
+            raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
+        dy2 = dy.reshape(M, H)
+        if not dy2.is_contiguous():
+            dy2 = dy2.contiguous()
+        dres = dy2                                                                        # the residual branch: y = x + ...
+        if ctx.drop_p > 0.0:
+            dmask = torch.empty_like(dy2)
+            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), H, ctx.drop_p, ctx.seed, _sp()), "dropout")
+            dy2 = dmask
+        # rebuild LayerNorm output, FFN pre-activation and GELU output
+        RECOMPUTE.active += 1
+        try:
+            ln, _, _ = _ln_forward(x2, gamma, beta, ctx.eps)
+            pre = torch.empty((M, F), dtype=BF16, device=dy.device)
+            inter = torch.empty((M, F), dtype=BF16, device=dy.device)
+            gemm_nt(ln, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
+        finally:
+            RECOMPUTE.active -= 1
+        db2 = torch.zeros(H, dtype=torch.float32, device=dy.device)
+        _accum_grad(w2, weight_grad_tn(dy2, inter, colsum=db2))
+        _accum_grad(b2, db2)
+        del inter
+        dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
+        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)         # (dy W2) * gelu'(pre) in the epilogue
+        del pre
+        db1 = torch.zeros(F, dtype=torch.float32, device=dy.device)
+        _accum_grad(w1, weight_grad_tn(dpre, ln, colsum=db1))
+        _accum_grad(b1, db1)
+        del ln
+        dln = matmul_nt(dpre, w_bf16_t(w1))
+        del dpre
+        dx = _ln_backward(dln, x2, gamma, beta, mean, rstd, dres)
+        return dx.reshape(ctx.shp), None, None, None, None, None, None, None, None, None
+
+
+def ln_mlp(x, gamma, beta, eps, w1, b1, w2, b2, drop_p=0.0, seed=0):
+    return LNMLPFn.apply(x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed)
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

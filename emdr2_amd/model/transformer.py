@@ -107,8 +107,8 @@ class ParallelAttention(torch.nn.Module):
         ph = self.hidden_dropout if self.training else 0.0
         seed = K.DROPOUT.seed(self._site_attn) if pa else 0
         if self.attention_type == "self":
-            mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm).view(lead + (3, self.heads, self.hn))
-            ctx = K.attention_core(mixed, None, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(x.shape)
+            mixed = K.linear(x, self.query_key_value.weight, self.query_key_value.bias, row_perm=self._perm)
+            return self.attend(mixed, ids_q, ids_k, causal, residual)
         else:
             if self.kv_cache is not None and self.kv_cache[0] is encoder_output:
                 kv = self.kv_cache[1]                                                     # K/V of the 25,600 encoder tokens, projected once
@@ -121,6 +121,15 @@ class ParallelAttention(torch.nn.Module):
             ctx = K.attention_core(q, kv, ids_q, ids_k, causal, drop_p=pa, seed=seed, site=self._site_attn).view(x.shape)
         return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
+
+    def attend(self, mixed, ids_q, ids_k, causal, residual):
+        """Self-attention from the packed QKV projection `mixed` [..., 3 h] on: fused attention, output projection, bias-dropout-add."""
+        lead = tuple(mixed.shape[:-1])
+        pa = self.attention_dropout if self.training else 0.0
+        ph = self.hidden_dropout if self.training else 0.0
+        ctx = K.attention_core(mixed.view(lead + (3, self.heads, self.hn)), None, ids_q, ids_k, causal, drop_p=pa,
+                               seed=K.DROPOUT.seed(self._site_attn) if pa else 0, site=self._site_attn).view(lead + (self.heads * self.hn,))
+        return K.linear(ctx, self.dense.weight, self.dense.bias, residual=residual, drop_p=ph, seed=K.DROPOUT.seed(self._site_out) if ph else 0)
 
     def step_self(self, x1, ids_cur, ids_block, pos, cache, residual):
         """One decoding step of SELF-attention with a K/V cache (the reference's `layer_past` / `get_key_value` plumbing,
@@ -146,6 +155,20 @@ class ParallelTransformerLayer(torch.nn.Module):
             self.inter_attention = ParallelAttention(cfg, out_std, "cross")
             self.post_inter_attention_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
         self.mlp = ParallelMLP(cfg, out_std)
+
+    def forward_selective(self, x, ids):
+        """The encoder layer with SELECTIVE activation retention (no per-layer checkpoint around it): what stays in HBM for the backward is
+        the layer input, the packed QKV projection, the attention output (+ its row statistics) and the attention block's output -- 6
+        [tokens, h] tensors instead of ~16; both LayerNorm outputs and the FFN's pre-activation / GELU output (9 of the 16) are rebuilt in
+        the backward by the LayerNorm kernel and one h -> 4h GEMM (kernels.LNLinearFn, kernels.LNMLPFn).  Same kernels, same dropout
+        streams, same results as `forward`."""
+        att, mlp = self.self_attention, self.mlp
+        ln1, ln2 = self.input_layernorm, self.post_attention_layernorm
+        mixed, res = K.ln_linear(x, ln1.weight, ln1.bias, ln1.eps, att.query_key_value.weight, att.query_key_value.bias, att._perm)
+        x = att.attend(mixed, ids, ids, False, residual=res)
+        p = mlp.hidden_dropout if self.training else 0.0
+        return K.ln_mlp(x, ln2.weight, ln2.bias, ln2.eps, mlp.dense_h_to_4h.weight, mlp.dense_h_to_4h.bias, mlp.dense_4h_to_h.weight,
+                        mlp.dense_4h_to_h.bias, drop_p=p, seed=K.DROPOUT.seed(mlp._site) if p else 0)
 
     def forward(self, x, ids, causal, encoder_output=None, enc_ids=None):
         # every LayerNorm hands the residual stream through, so the stream's gradient is folded into the LayerNorm backward kernel
@@ -192,14 +215,23 @@ class ParallelTransformer(torch.nn.Module):
         self.layers = torch.nn.ModuleList([ParallelTransformerLayer(cfg, out_std, layer_type) for _ in range(cfg.num_layers)])
         self.final_layernorm = LayerNorm(cfg.hidden_size, cfg.layernorm_epsilon)
         self.checkpoint_activations = checkpoint_activations
-        # With 288 GB of HBM not every layer has to be re-run in the backward: the LAST `keep_last` layers keep their activations (they are
-        # produced last and consumed first, so they cost the least peak memory per layer kept).  0 = the reference's --checkpoint-activations.
+        # With 288 GB of HBM not every layer has to be re-run in the backward (the reference's --checkpoint-activations re-runs all of them,
+        # mpu/random.py:245-319, transformer.py:621-646).  Counted from the END of the stack (produced last, consumed first: the least peak
+        # memory per layer): the last `keep_last` layers keep ALL their activations (~16 [tokens, h] tensors each); the `selective` layers
+        # before those keep 6 and rebuild the rest with a third of a layer forward (ParallelTransformerLayer.forward_selective; encoder
+        # stacks only); whatever is left in front is re-run whole.  0 / 0 = the reference's behaviour.
         self.keep_last = 0
+        self.selective = 0
 
     def forward(self, x, ids, causal=False, encoder_output=None, enc_ids=None):
-        n_recompute = len(self.layers) - int(self.keep_last)
+        n_layers = len(self.layers)
+        n_keep = min(int(self.keep_last), n_layers)
+        n_sel = min(int(self.selective), n_layers - n_keep) if encoder_output is None and not causal else 0
+        n_recompute = n_layers - n_keep - n_sel
         for li, layer in enumerate(self.layers):
-            if self.checkpoint_activations and torch.is_grad_enabled() and li < n_recompute:
+            if self.checkpoint_activations and torch.is_grad_enabled() and n_recompute <= li < n_recompute + n_sel:
+                x = layer.forward_selective(x, ids)
+            elif self.checkpoint_activations and torch.is_grad_enabled() and li < n_recompute:
                 # determinism_check off: the first run of a layer deliberately saves placeholders for tensors only its re-run needs (the
                 # FFN pre-activation), so saved-tensor shapes differ between the two runs by design; the COUNT and order stay equal
                 x = torch.utils.checkpoint.checkpoint(_CheckpointedLayer(layer), x, ids, causal, encoder_output, enc_ids, use_reentrant=False,

@@ -204,32 +204,38 @@ def test_dropout_is_reproduced_by_activation_recompute_and_changes_per_step():
 
 
 def test_keeping_the_last_layers_instead_of_recomputing_them_changes_nothing():
-    """ParallelTransformer.keep_last: the last n layers of a checkpointed stack keep their activations (288 GB of HBM) instead of being
-    re-run in the backward.  Same dropout masks, same gradients as full recompute."""
+    """ParallelTransformer.keep_last / .selective: the last n layers of a checkpointed stack keep ALL their activations, the `selective`
+    ones before them keep 6 [tokens, h] tensors and rebuild LayerNorm outputs + FFN intermediates in the backward (kernels.LNLinearFn /
+    LNMLPFn), the rest is re-run whole (the reference's --checkpoint-activations, mpu/random.py:245-319).  Same dropout masks, same
+    outputs, same gradients in every mix; the recomputed GEMM flops shrink accordingly."""
     from emdr2_amd.model import kernels as K
     from emdr2_amd.model.transformer import Config, T5Model
     rng = np.random.default_rng(6)
     enc_ids, dec_ids = _ids(rng, (8, 64), 512).cuda(), _ids(rng, (8, 32), 512).cuda()
-    grads, outs = [], []
+    grads, outs, redo = [], [], []
     K.ATTN_STASH.store.clear()                               # (entries other tests left behind by running a forward without its backward)
-    for keep in (0, 1, 3):
+    for keep, sel in ((0, 0), (1, 0), (3, 0), (0, 3), (1, 2), (0, 1)):
         torch.manual_seed(0)
         K.DROPOUT._sites = 0
         cfg = Config(num_layers=3, hidden_size=128, num_attention_heads=2, ffn_hidden_size=256, max_position_embeddings=128, init_method_std=0.05,
                      hidden_dropout=0.1, attention_dropout=0.1)
         m = T5Model(cfg, 512, checkpoint_activations=True)
-        m.language_model.encoder.keep_last = keep
+        m.language_model.encoder.keep_last, m.language_model.encoder.selective = keep, sel
         m.train()
         K.DROPOUT.step = 2
+        K.RECOMPUTE.flops = 0.0
         logits, _ = m(enc_ids, dec_ids)
         logits.float().square().mean().backward()
         assert len(K.ATTN_STASH.store) == 0
         outs.append(logits.detach().float())
         grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
-    for i in (1, 2):
+        redo.append(K.RECOMPUTE.flops)
+    for i in range(1, len(outs)):
         assert torch.equal(outs[0], outs[i])
         for k in grads[0]:
             assert _rel(grads[i][k], grads[0][k]) < 1e-3, (i, k)
+    # encoder recompute: 3 layers whole > 2 whole > 1 selective + ... ; all three selective = a third of the linear flops of three re-runs
+    assert redo[0] > redo[1] > redo[2] and redo[0] > redo[5] > redo[3] > redo[2]
 
 
 def test_attention_stash_under_checkpointing_gives_identical_gradients():
