@@ -49,7 +49,7 @@ def parse():
     ap.add_argument("--queries", type=int, default=512)
     ap.add_argument("--topk", type=int, default=50)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="MIPS half only")
     ap.add_argument("--e2e-steps", type=int, default=3)
     ap.add_argument("--e2e-warmup", type=int, default=1)
@@ -269,7 +269,7 @@ def main():
             ctx = bench_e2e.setup(args, rank, world, index=index, topk=k)
             e2e = bench_e2e.run(ctx, args.e2e_steps, args.e2e_warmup, world)
             if rank == 0 and world == 1 and not args.no_cpu_baseline:
-                e2e["cpu_baseline"] = bench_e2e.cpu_baseline_subprocess(args.cpu_seconds)
+                e2e["cpu_baseline"] = bench_e2e.cpu_baseline_subprocess(min(args.cpu_seconds, 10.0), threads=result.get("cpu_baseline", {}).get("cores", 0))
         except Exception as exc:                      # the MIPS half is still reported
             e2e = {"error": "%s: %s" % (type(exc).__name__, exc)}
         if watchdog is not None:

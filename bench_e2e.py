@@ -289,27 +289,30 @@ def run(ctx, steps, warmup, world):
     }
 
 
-def cpu_baseline_subprocess(seconds=12.0, limit=120.0):
-    """cpu_baseline_model in a child process with a hard wall-clock limit (a slow host must not cost the benchmark its JSON line)."""
+def cpu_baseline_subprocess(seconds=12.0, limit=120.0, threads=0):
+    """cpu_baseline_model in a child process with a hard wall-clock limit (a slow host must not cost the benchmark its JSON line).
+    `threads`: the count the MIPS leg's sweep found fastest on this host (0 = decide here between 32 and 64)."""
     import subprocess
     env = dict(os.environ, HIP_VISIBLE_DEVICES="", CUDA_VISIBLE_DEVICES="")
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
         env.pop(k, None)
     try:
-        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds)], env=env, timeout=limit,
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-only", "--cpu-seconds", str(seconds), "--cpu-threads", str(threads)],
+                             env=env, timeout=limit,
                              stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, check=True).stdout.decode()
         return json.loads(out.strip().splitlines()[-1])
     except Exception as exc:
         return {"error": "%s: %s" % (type(exc).__name__, exc)}
 
 
-def cpu_baseline_model(seconds=20.0, layers=12, max_threads=64):
+def cpu_baseline_model(seconds=12.0, layers=12, threads=0):
     """The model path on the host cores: the torch-fp32 oracle restatement of the reference's forward / loss (oracle.transformer_oracle,
     pinned on the reference's modules) + autograd backward at the BASELINE architecture (all 12 layers of every stack, H = 768, 12 heads,
     FFN 3072, S_ret 256, S 512, L 32, full vocabularies) on a BOUNDED sample -- B = 1 question, K = 2 passages -- so the factor to the
-    B = 64, K = 50 step is batch only (dense-GEMM flops).  kind "port".  Threads: the faster of 32 / `max_threads` on the first steps."""
+    B = 64, K = 50 step is batch only (dense-GEMM flops).  kind "port".  Threads: `threads` (what the MIPS leg's sweep found fastest on
+    this host), else 32 -- GEMMs of a 2,000-token batch on hundreds of threads run slower than on a few dozen."""
     from oracle import transformer_oracle as to
-    cores = min(os.cpu_count() or 1, max_threads)
+    cores = min(os.cpu_count() or 1, threads if threads > 0 else 32)
     torch.set_num_threads(cores)
     cfg = dict(layers=layers, hidden=H, heads=12, ffn=3072)
     P = {k: v.requires_grad_(True) for k, v in to.random_params(cfg, V_BERT, V_T5).items()}
@@ -331,25 +334,15 @@ def cpu_baseline_model(seconds=20.0, layers=12, max_threads=64):
         loss = to.reader_ce_loss(lm, labels, mask) + to.retriever_loss_and_utility(oc, tlp, labels, mask, 30523)[0]
         loss.backward()
     t0 = time.perf_counter(); step(); t_first = time.perf_counter() - t0          # includes allocator warm-up
-    tried = {cores: None}
-    if cores > 32:                                                                # one step at 32 threads: keep whichever count is faster
-        t0 = time.perf_counter(); step(); tried[cores] = time.perf_counter() - t0
-        torch.set_num_threads(32)
-        step()
-        t0 = time.perf_counter(); step(); tried[32] = time.perf_counter() - t0
-        cores = min(tried, key=tried.get)
-        torch.set_num_threads(cores)
     reps, t = 0, 0.0
-    spent = time.perf_counter()
-    while reps < 1 or (t / reps * (reps + 1) + t_first + sum(v or 0 for v in tried.values()) * 1.5 < seconds and reps < 3):
+    while reps < 1 or (t_first + t / reps * (reps + 1) < seconds and reps < 3):
         t0 = time.perf_counter(); step(); t += time.perf_counter() - t0; reps += 1
     per = t / reps
     scale = flops_per_step(64, 50, S_ret, S, L, H, V_T5, 12) / flops_per_step(B, K, S_ret, S, L, H, V_T5, layers)
     return {"value": 1.0 / (per * scale), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": "%d step(s) of the fp32 oracle (forward + loss + autograd backward, Adam excluded) at B=%d, K=%d, S_ret %d, S %d, L %d, "
-                      "%d of 12 layers per stack, torch CPU, %d threads (tried: %s): %.2f s/step; scaled x%.0f by dense-GEMM flops to B=64, K=50"
-                      % (reps, B, K, S_ret, S, L, layers, cores, ", ".join("%d -> %s" % (k, "%.2f s" % v if v else "first") for k, v in sorted(tried.items())),
-                         per, scale)}
+                      "%d of 12 layers per stack, torch CPU, %d threads: %.2f s/step (first, untimed: %.2f s); scaled x%.0f by dense-GEMM flops to "
+                      "B=64, K=50" % (reps, B, K, S_ret, S, L, layers, cores, per, t_first, scale)}
 
 
 def main():
@@ -362,10 +355,11 @@ def main():
     ap.add_argument("--cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="print the host-core baseline of the model path as JSON and exit (no GPU)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--cpu-threads", type=int, default=0)
     add_args(ap)
     args = ap.parse_args()
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline_model(args.cpu_seconds)), flush=True)
+        print(json.dumps(cpu_baseline_model(args.cpu_seconds, threads=args.cpu_threads)), flush=True)
         return
     from emdr2_amd import dist_util
     rank, world, _ = dist_util.init_distributed()
