@@ -23,7 +23,7 @@ M_FULL = 3200 * 512
 LAUNCHES = 3
 # (kind, M, N, K, epilogue)
 CONFIGS = [("nt", M_FULL, N, K, e) for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))
-           for e in ("plain", "bias", "bias+gelu", "bias+res", "bias+drop+res", "gelu'")] + \
+           for e in ("plain", "bias", "bias+gelu", "bias+gelu+pre", "bias+res", "bias+drop+res", "gelu'")] + \
           [("tn", M_FULL, N, K, "colsum") for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))]
 
 
@@ -47,6 +47,7 @@ def run():
                 K.weight_grad_tn(b, a, colsum=bias)          # dW [N, K] = dy [M, N]^T x [M, K]
             else:
                 kw = {}
+                if "pre" in epi.split("+"): kw["pre_act"] = r                   # (the pre-activation output: same size as the residual buffer)
                 if "bias" in epi: kw["bias"] = bias
                 if "gelu" in epi.split("+"): kw["gelu"] = True
                 if "res" in epi.split("+"): kw["residual"] = r
@@ -86,14 +87,22 @@ def summarize(dirs, shapes_json, out):
         cfg["ms_per_launch_under_pmc"] = round(ms, 3)
         cfg["tflops_under_pmc"] = round(fl / (ms * 1e-3) / 1e12, 1)
         c = cfg["counters"]
-        algo = 2.0 * (cfg["M"] * cfg["K"] + cfg["N"] * cfg["K"] + cfg["M"] * cfg["N"]) if cfg["kind"] == "nt" else 2.0 * cfg["M"] * (cfg["N"] + cfg["K"])
-        if "res" in cfg["epilogue"] or cfg["epilogue"] == "gelu'":
-            algo += 2.0 * cfg["M"] * cfg["N"]
-        cfg["algorithmic_hbm_gb"] = round(algo / 1e9, 3)
+        # algorithmic bytes, reads and writes apart: operands (+ the residual / saved pre-activation the epilogue reads) in, outputs out
+        if cfg["kind"] == "nt":
+            rd = 2.0 * (cfg["M"] * cfg["K"] + cfg["N"] * cfg["K"])
+            wr = 2.0 * cfg["M"] * cfg["N"] * (2 if "pre" in cfg["epilogue"].split("+") else 1)
+            if "res" in cfg["epilogue"].split("+") or cfg["epilogue"] == "gelu'":
+                rd += 2.0 * cfg["M"] * cfg["N"]
+        else:
+            rd, wr = 2.0 * cfg["M"] * (cfg["N"] + cfg["K"]), 4.0 * cfg["N"] * cfg["K"]
+        cfg["algorithmic_read_gb"], cfg["algorithmic_write_gb"] = round(rd / 1e9, 3), round(wr / 1e9, 3)
+        cfg["algorithmic_hbm_gb"] = round((rd + wr) / 1e9, 3)
         if "FETCH_SIZE" in c:
             cfg["hbm_read_gb"] = round(2.0 * c["FETCH_SIZE"] * 1024 / 1e9, 3)          # KB, x2: gfx950 tallies 128-B read requests at 64 B
+            cfg["read_ratio"] = round(cfg["hbm_read_gb"] / cfg["algorithmic_read_gb"], 3)
         if "WRITE_SIZE" in c:
             cfg["hbm_write_gb_uncalibrated"] = round(c["WRITE_SIZE"] * 1024 / 1e9, 3)
+            cfg["write_ratio_uncalibrated"] = round(cfg["hbm_write_gb_uncalibrated"] / cfg["algorithmic_write_gb"], 3)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # MFMA-busy cycles are summed over the 1,024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
             cfg["mfma_busy_frac"] = round(c["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / (c["GRBM_GUI_ACTIVE"] / 8.0), 3)
@@ -109,7 +118,31 @@ def summarize(dirs, shapes_json, out):
                      "clock the launch actually ran at (shader_clock_ghz; the 2.5 PFLOP/s peak assumes 2.4 GHz)"],
            "per_kernel": per}
     if shapes_json and os.path.exists(shapes_json):
-        res["end_to_end_step"] = json.load(open(shapes_json))
+        step = json.load(open(shapes_json))
+        res["end_to_end_step"] = step
+        # step-weighted traffic: every GEMM launch of the step takes the read / write ratio measured for its (kind, N, K, epilogue) above,
+        # weighted by its own algorithmic bytes (M differs per stack: the ratios are per byte, not per launch)
+        by = {(c["kind"], c["N"], c["K"], c["epilogue"]): c for c in per if "read_ratio" in c}
+        tot = {"algorithmic_read_gb": 0.0, "measured_read_gb": 0.0, "algorithmic_write_gb": 0.0, "measured_write_gb_uncalibrated": 0.0, "covered_ms": 0.0, "all_ms": 0.0}
+        for r in step["shapes"]:
+            tot["all_ms"] += r["ms"]
+            epi = {"colsum": "colsum", "plain": "plain"}.get(r["epilogue"], r["epilogue"])
+            c = by.get((r["kind"], r["N"], r["K"], epi))
+            if c is None or r.get("batch", 1) != 1:
+                continue
+            if r["kind"] == "nt":
+                rd = 2.0 * (r["M"] * r["K"] + r["N"] * r["K"]) + (2.0 * r["M"] * r["N"] if ("res" in epi.split("+") or epi == "gelu'") else 0.0)
+                wr = 2.0 * r["M"] * r["N"] * (2 if "pre" in epi.split("+") else 1)
+            else:
+                rd, wr = 2.0 * r["M"] * (r["N"] + r["K"]), 4.0 * r["N"] * r["K"]
+            n = r["launches"]
+            tot["algorithmic_read_gb"] += n * rd / 1e9; tot["measured_read_gb"] += n * rd / 1e9 * c["read_ratio"]
+            tot["algorithmic_write_gb"] += n * wr / 1e9; tot["measured_write_gb_uncalibrated"] += n * wr / 1e9 * c.get("write_ratio_uncalibrated", 1.0)
+            tot["covered_ms"] += r["ms"]
+        tot = {k: round(v, 2) for k, v in tot.items()}
+        tot["read_ratio"] = round(tot["measured_read_gb"] / max(tot["algorithmic_read_gb"], 1e-9), 3)
+        tot["write_ratio_uncalibrated"] = round(tot["measured_write_gb_uncalibrated"] / max(tot["algorithmic_write_gb"], 1e-9), 3)
+        res["step_weighted_traffic"] = tot
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
     for cfg in per:

@@ -28,6 +28,11 @@ def main():
     torch.cuda.set_device(0)
     from emdr2_amd.model import kernels as K
     ctx = bench_e2e.setup(args, 0, 1, topk=args.topk)
+    if args.selective_layers != "auto":                       # the retention plan bench.py's auto policy picks on a 288 GB box: pass it explicitly
+        sel_r, sel_c = (int(v) for v in args.selective_layers.split(","))
+        ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
+    if args.keep_last_layers != "auto":
+        ctx.model.set_recompute_keep_last(int(args.keep_last_layers))
     records = []
     live = {"on": False}
 
