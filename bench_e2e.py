@@ -157,7 +157,7 @@ def choose_retention(ctx, world):
     # what the full-recompute step needed, plus the caching allocator's overhead (measured: reserved = 1.08 x allocated at the peak), plus a
     # margin: packed token counts -- and with them every activation size -- move by a fraction of a percent from step to step
     peak = int(torch.cuda.max_memory_allocated() * 1.08)
-    spare = (25 << 30) if not Kmod.PACKING.enabled else (28 << 30)
+    spare = (25 << 30) if not Kmod.PACKING.enabled else (22 << 30)
     budget = max(0, int((capacity - spare - peak) / 1.08))
     hist = [(S, rows) for n, S, rows in Kmod.PACKING.history if n == ctx.B * ctx.K] if Kmod.PACKING.enabled else []
     rows_reader = max([r for S, r in hist if S == ctx.S] + [0]) or ctx.B * ctx.K * ctx.S                 # (the larger of the two S-long stacks: qext)
@@ -167,11 +167,11 @@ def choose_retention(ctx, world):
         sel_r, sel_c = (int(v) for v in str(want_sel).split(","))
     else:
         # measured at B = 64, K = 50: 6.3 GB per selective reader-encoder layer (3.2 tensors of [1.29M, 768] bf16 over a checkpointed one),
-        # 3.0 GB per context-tower layer (4.4 tensors of [0.44M, 768]); a fully kept layer 14.5 GB (7.3 tensors): budgeted at 3.6 / 4.8 / 8.0
-        sel_r = int(min(L, budget // (3.6 * unit_r)))
-        budget -= sel_r * 3.6 * unit_r
-        sel_c = int(min(L, budget // (4.8 * unit_c))) if sel_r == L else 0
-        budget -= sel_c * 4.8 * unit_c
+        # 3.0 GB per context-tower layer (4.4 tensors of [0.44M, 768]); a fully kept layer 14.5 GB (7.3 tensors): budgeted at 3.3 / 4.6 / 8.0
+        sel_r = int(min(L, budget // (3.3 * unit_r)))
+        budget -= sel_r * 3.3 * unit_r
+        sel_c = int(min(L, budget // (4.6 * unit_c))) if sel_r == L else 0
+        budget -= sel_c * 4.6 * unit_c
     if want_keep != "auto":
         keep = max(0, min(int(want_keep), L))
     else:
@@ -249,6 +249,21 @@ def run(ctx, steps, warmup, world):
         allcs = [torch.empty_like(cs) for _ in range(world)]
         torch.distributed.all_gather(allcs, cs)
         replicas = [float(c.item()) for c in allcs]
+    # HBM traffic of the step's GEMM launches: per-kernel FETCH_SIZE x 2 / WRITE_SIZE (separate rocprofv3 --pmc passes over the kernels one by
+    # one, tools/r03_gemm_evidence.sh) weighted by the algorithmic bytes of every GEMM launch of a step -- committed summary, not measured live
+    traffic, traffic_note = None, "profiles/r03_gemm_summary.json not found"
+    prof = os.path.join(ROOT, "profiles", "r03_gemm_summary.json")
+    if os.path.exists(prof):
+        sw = json.load(open(prof)).get("step_weighted_traffic")
+        if sw:
+            traffic = {"hbm_read_gb_per_step": sw["measured_read_gb"], "algorithmic_read_gb_per_step": sw["algorithmic_read_gb"], "read_ratio": sw["read_ratio"],
+                       "hbm_write_gb_per_step_uncalibrated": sw["measured_write_gb_uncalibrated"], "algorithmic_write_gb_per_step": sw["algorithmic_write_gb"],
+                       "write_ratio_uncalibrated": sw["write_ratio_uncalibrated"]}
+            traffic_note = ("step-weighted over the GEMM launches of one step (%.0f of %.0f ms covered) from profiles/r03_gemm_summary.json: per (kind, N, K, "
+                            "epilogue) FETCH_SIZE x 2 (the gfx950 correction for 16-byte LDS-DMA streams; the epilogues' residual / pre-activation rows are read "
+                            "with another access shape for which the x 2 is uncalibrated, so their ratios -- and this aggregate -- are upper bounds) and "
+                            "WRITE_SIZE; operand-only kernels: 1.16 (N = K = 768), 1.34 (K = 3072), 2.4 - 3.8 (N = 2304 / 3072: B panels re-fetched once "
+                            "per round and XCD, DESIGN.md 11)" % (sw["covered_ms"], sw["all_ms"]))
     fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)
     sps = steps / elapsed
     gemm_ms, gemm_fl = ms[0] + ms[1], fl[0] + fl[1]
@@ -275,9 +290,7 @@ def run(ctx, steps, warmup, world):
                    "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
                    "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
         # dominant kernels of the step: the dense linears (NT GEMM forward / input gradients, TN GEMM weight gradients)
-        "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_PEAK_TFLOPS, "traffic": None,
-                     "traffic_note": "an aggregate over ~1,040 launches of 40 shapes has no per-launch byte count; FETCH_SIZE / WRITE_SIZE per shape and kernel: "
-                                     "profiles/r02_gemm_summary.json (per_kernel[*].hbm_read_gb against algorithmic_hbm_gb)",
+        "roofline": {"bound": "mfma", "achieved": gemm_tf, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_PEAK_TFLOPS, "traffic": traffic, "traffic_note": traffic_note,
                      "kernel": "gemm_nt (gemm8_kernel / gemm_nt_kernel) + gemm_tn_kernel: executed flops / summed per-launch hipEvent time (rank 0)",
                      "per_step": {k: {"ms": ms[i] / steps, "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0), "launches": int(nl[i] // steps)}
                                   for i, k in enumerate(kinds)},

@@ -254,11 +254,12 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
 template <bool DROP, bool CAUSAL>
 __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(BwdParams p)
 {
-    // 2 stages x (Q tile 8 KiB + dO tile 8 KiB); per-query statistics of the block: pm, D, row hash, flags (64 each)
-    __shared__ __attribute__((aligned(16))) char smem[2 * 16384];
-    __shared__ __attribute__((aligned(16))) float st_pm[2][64], st_d[2][64];
-    __shared__ __attribute__((aligned(16))) uint32_t st_rh[2][64];
-    __shared__ unsigned long long st_qreal[2];
+    // 3 stages x (Q tile 8 KiB + dO tile 8 KiB): two blocks of DMA in flight while one is consumed (as in attention.hip); per-query
+    // statistics of a block: pm, D, row hash, flags (64 each)
+    __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
+    __shared__ __attribute__((aligned(16))) float st_pm[3][64], st_d[3][64];
+    __shared__ __attribute__((aligned(16))) uint32_t st_rh[3][64];
+    __shared__ unsigned long long st_qreal[3];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -287,7 +288,8 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
             __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + KNW * i) * 1024), 16, 0, 0);
         }
     };
-    issue(0, 0);                     // first Q / dO block in flight before this wave's K / V rows and the statistics are fetched
+    issue(0, 0);                     // first Q / dO blocks in flight before this wave's K / V rows and the statistics are fetched
+    if (nblk > 1) issue(1, 1);
 
     bf16x8 kf[4], vf[4];
     load_row_frags(p.k + (ex.k_off + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
@@ -329,14 +331,25 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const bool codd = kc & 1;
 
     if (wave == 0) { load_stats(0); store_stats(0); if (nblk > 1) load_stats(1); }
-    for (int blk = 0; blk < nblk; ++blk) {
-        const int stage = blk & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (blk + 1 < nblk) {
-            if (wave == 0) store_stats(stage ^ 1);
-            issue(blk + 1, stage ^ 1);
-            if (wave == 0 && blk + 2 < nblk) load_stats(blk + 2);
+    // everything fetched so far is complete here, in a form the compiler sees (cf. attention.hip): no hidden vmcnt(0) inside the loop
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]),
+                 "+v"(nx_pm), "+v"(nx_d), "+v"(nx_rh)::"memory");
+    int stage = 0;
+    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
+        // all but the newest block's DMA pieces (2 x 8 / KNW instructions of this wave): this block's tiles -- and, on wave 0, the statistics
+        // of the next block, which were requested BEFORE that DMA -- have arrived
+        if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / KNW)) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // raw barrier: a fence would drain the look-ahead DMA
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        {
+            const int nstage = stage == 2 ? 0 : stage + 1;
+            if (blk + 1 < nblk && wave == 0) store_stats(nstage);                 // block blk + 1 (its row statistics came in an iteration ago)
+            if (blk + 2 < nblk) {
+                if (wave == 0) load_stats(blk + 2);                               // ... requested before the DMA of the same block
+                issue(blk + 2, stage == 0 ? 2 : stage - 1);
+            }
         }
         const int qb0 = blk * 64;
         // keys of this wave all ahead of every query of the block: P == 0 exactly and dS == 0
