@@ -144,3 +144,27 @@ def test_lm_head_fused_with_log_softmax_gather(M, V, H):
         ref = torch.log_softmax(hid.float() @ W.bfloat16().float().T + bias, dim=-1).gather(1, labels[:, None])[:, 0]
     assert torch.allclose(fused, unfused, rtol=0, atol=2e-4), float((fused - unfused).abs().max())   # same bf16-rounded logits, different summation order
     assert torch.allclose(fused, ref, rtol=2e-2, atol=5e-2)
+
+
+def test_lm_head_fused_loss_with_labels_outside_the_vocabulary():
+    """a label the epilogue never meets (negative: an ignore_index such as -100; or >= V) must not read uninitialised memory:
+    gold is 0 for such a row, so the result is exactly -logsumexp(row), deterministically; in-range rows are unaffected."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, V, H = 512, 1024, 128
+    hid = _rand((M, H), g)
+    W = torch.nn.Parameter(torch.randn((V, H), generator=g, device="cuda") * 0.05)
+    bias = torch.nn.Parameter(torch.randn(V, generator=g, device="cuda") * 0.1)
+    labels = torch.randint(0, V, (M,), generator=g, device="cuda")
+    labels[3], labels[100], labels[511] = -100, V, V + 7
+    with torch.no_grad():
+        torch.empty(M * 64, device="cuda").fill_(float("nan"))           # poison what the allocator hands out next
+        a = K.lm_head_gold_logprob(hid, W, bias, labels)
+        b = K.lm_head_gold_logprob(hid, W, bias, labels)
+        lse = torch.logsumexp(K.linear(hid, W, bias).float(), dim=-1)
+    assert torch.equal(a, b) and bool(torch.isfinite(a).all())
+    out = torch.tensor([3, 100, 511], device="cuda")
+    assert torch.allclose(a[out], -lse[out], atol=2e-4)
+    inside = torch.ones(M, dtype=torch.bool, device="cuda"); inside[out] = False
+    ref = K.lse_gather(K.linear(hid, W, bias), labels.clamp(0, V - 1))
+    assert torch.allclose(a[inside], ref[inside], atol=2e-4)

@@ -407,7 +407,7 @@ def test_embedding_backward_with_token_types_and_positions():
     assert float(Pt.grad[s:].abs().max()) == 0.0                          # rows beyond the sequence length untouched
 
 
-@pytest.mark.parametrize("B,Kk,H,scaled", [(64, 50, 768, True), (8, 101, 768, True), (3, 7, 128, False), (5, 128, 64, True)])
+@pytest.mark.parametrize("B,Kk,H,scaled", [(64, 50, 768, True), (8, 101, 768, True), (3, 7, 128, False), (5, 128, 64, True), (4, 129, 64, True), (2, 1000, 128, True)])
 def test_retriever_prior_kernel_value_and_gradients(B, Kk, H, scaled):
     """a9 (emdr2_model.py:134-145): log_softmax_k(<q, c_k> / sqrt(H)) and its gradients against torch fp32 autograd of the same formula."""
     from emdr2_amd.model import kernels as K
