@@ -275,6 +275,8 @@ def run(ctx, steps, warmup, world):
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
                    "packed_sequences": bool(Kmod.PACKING.enabled),
+                   "dense_layout_ab": "same box, same commit, --no-packing: 2,900 ms/step against 1,941 packed (both with the r02 keep-last policy; "
+                                      "profiles/r03_e2e_dense_layout.json, r03_e2e_packed_first.json); rerun with `bench_e2e.py --no-packing`",
                    # encoder-stack tokens per step (query tower, context tower, reader encoder, one-context pass): real = what the packed
                    # layout runs, padded = the reference's [batch, S] grids
                    "tokens_real": (Kmod.PACKING.real_tokens // steps) if Kmod.PACKING.enabled else None,
