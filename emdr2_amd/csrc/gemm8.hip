@@ -44,7 +44,7 @@ struct G8Params {
     float drop_p;
     uint32_t seed;
     int tiles_m, tiles_n, ngroup, total, per;   // tile order: `per` consecutive sequence positions per XCD
-    uint32_t mg_full, mg_group, mg_last;        // ceil(2^32 / d) for d = ngroup * tiles_m, ngroup, width of the last group (exact quotients for < 2^24)
+    uint32_t mg_full, mg_group, mg_last;        // ceil(2^32 / d) for d = ngroup * tiles_m, ngroup, width of the last group (tile_coords corrects the +1)
     // LSE mode (lse_part != nullptr): nothing is stored to C; per (row, n-tile) partial max / sum-exp and the gold logit are written instead
     float *lse_max, *lse_sum, *lse_gold;
     const long long *labels;
@@ -57,11 +57,17 @@ __device__ __forceinline__ void tile_coords(const G8Params &p, int pos, int &tm,
 {
     // n-tiles in groups of `ngroup` B panels that fit the L2; inside a group the walk is n-fastest (gemm.hip has the rationale)
     const int full = p.ngroup * p.tiles_m;
-    const int g = (int)__umulhi((uint32_t)pos, p.mg_full), r = pos - g * full;
+    // quotient by the rounded-up reciprocal ceil(2^32 / d): never too small, and too large by at most one (the excess is < pos / 2^32 < 1) --
+    // which it IS once pos * (mg * d - 2^32) reaches 2^32, e.g. from tile 59,075 on for d = 6 x 12,800 tiles (M = 3.3M rows, N = 3072: top-k
+    // 100): one compare puts it right for every pos < 2^32
+    int g = (int)__umulhi((uint32_t)pos, p.mg_full);
+    if (g * full > pos) --g;
+    const int r = pos - g * full;
     const bool whole = (g + 1) * p.ngroup <= p.tiles_n;
     const int gsize = whole ? p.ngroup : p.tiles_n - g * p.ngroup;
     const uint32_t mg = whole ? p.mg_group : p.mg_last;
     tm = mg ? (int)__umulhi((uint32_t)r, mg) : r;             // mg == 0 encodes a divisor of 1
+    if (tm * gsize > r) --tm;
     tn = g * p.ngroup + (r - tm * gsize);
 }
 

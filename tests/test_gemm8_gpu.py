@@ -168,3 +168,24 @@ def test_lm_head_fused_loss_with_labels_outside_the_vocabulary():
     inside = torch.ones(M, dtype=torch.bool, device="cuda"); inside[out] = False
     ref = K.lse_gather(K.linear(hid, W, bias), labels.clamp(0, V - 1))
     assert torch.allclose(a[inside], ref[inside], atol=2e-4)
+
+
+def test_persistent_gemm_tile_order_at_three_million_rows():
+    """M = 3,276,800 rows (B = 64 x top-k 100 x S 512: the TriviaQA shape) x N = 1536: 76,800 tiles in ONE n-group.  The tile walk divides by
+    the rounded-up reciprocal of 6 x 12,800; uncorrected, that quotient is one too large from tile 59,075 on (an out-of-range tile: a
+    memory fault at top-k 100).  Sampled row blocks against fp32 torch."""
+    from emdr2_amd.model import kernels as K
+    g = torch.Generator(device="cuda").manual_seed(11)
+    M, N, Kd = 64 * 100 * 512, 1536, 128
+    a = (torch.randn((M, Kd), generator=g, device="cuda") * 0.5).bfloat16()
+    b = (torch.randn((N, Kd), generator=g, device="cuda") * 0.5).bfloat16()
+    bias = torch.randn(N, generator=g, device="cuda")
+    c = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    K.gemm_nt(a, Kd, b, Kd, c, N, M, N, Kd, bias=bias)
+    torch.cuda.synchronize()
+    for r0 in (0, 59_075 // 6 * 256, M // 2, M - 256):
+        ref = a[r0:r0 + 256].float() @ b.float().T + bias
+        got = c[r0:r0 + 256].float()
+        assert bool(torch.isfinite(got).all()), r0
+        assert torch.allclose(got, ref, rtol=2e-2, atol=5e-2), (r0, float((got - ref).abs().max()))
+    assert bool(torch.isfinite(c[::4099].float()).all())                      # every tile was written (no NaN left from the fill)
