@@ -16,12 +16,17 @@ ap.add_argument("--out", default="")
 args = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = bench_e2e.setup(args, 0, 1, topk=args.topk)
+if args.selective_layers != "auto":                           # e.g. --selective-layers 12,8: the plan bench.py picks on a 288 GB box
+    sel_r, sel_c = (int(v) for v in args.selective_layers.split(","))
+    ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
 losses, t0 = [], time.perf_counter()
 for i in range(args.steps):
     loss = ctx.step()
     losses.append(float(loss.detach()))
 torch.cuda.synchronize()
-res = {"workload": "bench_e2e.py step, B=%d, top-k %d, %d layers, %d-row index, lr warm-up 10 steps to 2e-5, dropout %.1f" % (ctx.B, ctx.K, ctx.layers, ctx.rows, ctx.dropout),
+from emdr2_amd.model import kernels as Kmod
+res = {"workload": "bench_e2e.py step, B=%d, top-k %d, %d layers, %d-row index, lr warm-up 10 steps to 2e-5, dropout %.1f, packed sequences %s, selective retention %s"
+                   % (ctx.B, ctx.K, ctx.layers, ctx.rows, ctx.dropout, Kmod.PACKING.enabled, args.selective_layers),
        "loss_per_step": losses, "seconds": time.perf_counter() - t0}
 print(json.dumps(res))
 if args.out:
