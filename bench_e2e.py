@@ -86,6 +86,7 @@ def setup(args, rank, world, index=None, topk=50):
 
     B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
     Kmod.PACKING.enabled = not getattr(args, "no_packing", False)
+    Kmod.PACKING.sticky, Kmod.PACKING.capacity = True, {}    # constant activation sizes from step to step (allocator reuse)
     if index is None:
         index = build_index(args.rows, rank, world)
     arena = EvidenceArena.synthetic(args.rows)
@@ -127,6 +128,19 @@ def setup(args, rank, world, index=None, topk=50):
                     labels=labels, mask=(labels != 0).float())
 
     def step():
+        try:
+            return step_once()
+        except torch.cuda.OutOfMemoryError:                               # allocator fragmentation: give the blocks back and run the step again
+            import gc
+            opt.zero_grad()
+            gc.collect()
+            torch.cuda.empty_cache()
+            oom_retries[0] += 1
+            return step_once()
+
+    oom_retries = [0]
+
+    def step_once():
         if indexer is not None:
             indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
@@ -139,7 +153,7 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
@@ -285,7 +299,7 @@ def run(ctx, steps, warmup, world):
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
                                            ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
                                             "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),
-                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12,
+                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.oom_retries[0],
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()), "replica_parameter_checksums": replicas,
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),

@@ -201,6 +201,12 @@ class _Packing(object):
         self.enabled = True
         self.real_tokens = self.grid_tokens = 0          # running totals over the layouts built so far (bench: tokens_real / tokens_padded)
         self.history = []                                # (n, S, rows) of the most recent layouts (bench: activation budget per stack)
+        # Training loops set `sticky`: the row count of a large stack then never shrinks and grows in 16,384-row steps, per (n, S, fill
+        # octile) -- after a few steps every activation of the stack has the SAME size step after step, which is what lets the caching
+        # allocator reuse its blocks (real-token counts move by a fraction of a percent per step; with free-running sizes two or three size
+        # classes of every transient tensor pile up: 58-68 GB "reserved but unallocated" and an out-of-memory after ~10 steps at 230 GB)
+        self.sticky = False
+        self.capacity = {}
 
 
 PACKING = _Packing()
@@ -236,6 +242,13 @@ class PackedSeqs(object):
         # steps -- whose real-token counts differ by a fraction of a percent -- repeat and the caching allocator reuses its blocks
         m = self.ROW_MULTIPLE if self.total < (1 << 16) else (8192 if self.total < (1 << 20) else 16384)
         self.rows = (self.total + m - 1) // m * m
+        if PACKING.sticky and self.total >= (1 << 16):
+            key = (n, S, int(8.0 * self.total / (n * S)))
+            cap = PACKING.capacity.get(key, 0)
+            if self.rows > cap:
+                cap = self.rows + (16384 if cap else 0)      # a new maximum: one granule of head-room so that the next one rarely follows
+                PACKING.capacity[key] = cap
+            self.rows = cap
         PACKING.history = PACKING.history[-15:] + [(n, S, self.rows)]
         self.rowmap = torch.empty(self.rows, dtype=torch.int32, device=dev)         # packed row -> dense row (i * S + pos), -1 in the tail
         self.inverse = torch.empty(n * S, dtype=torch.int32, device=dev)            # dense row -> packed row, -1 at dropped pad rows

@@ -148,6 +148,12 @@ def accuracy_func_provider(single_dataset_provider, datapath, tokenizer):
 
 
 def setup_model_and_optimizer(model_provider):
+    from emdr2_amd.model import kernels as _K
+    _K.PACKING.sticky = True                                  # training: packed stacks keep constant sizes from step to step (kernels._Packing)
+    return _setup_model_and_optimizer(model_provider)
+
+
+def _setup_model_and_optimizer(model_provider):
     """megatron/training.py:136-162: model, FusedAdam over the (decay / no-decay) groups, AnnealingLR, resume or pre-trained init."""
     args = get_args()
     model = model_provider()
