@@ -328,6 +328,13 @@ class cross_kv_cache(object):
             a.kv_cache = (None, None)
         return self
 
+    def expand(self, old_encoder_output, new_encoder_output, parent):
+        """Beam search: the encoder states were re-gathered along the batch (new = old[parent]); carry the cached K/V along instead of
+        projecting them again."""
+        for a in self.attn:
+            if a.kv_cache[0] is old_encoder_output:
+                a.kv_cache = (new_encoder_output, a.kv_cache[1].index_select(0, parent))
+
     def __exit__(self, *exc):
         for a in self.attn:
             a.kv_cache = None

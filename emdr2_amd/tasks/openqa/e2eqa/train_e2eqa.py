@@ -78,18 +78,23 @@ def build_data_loader(dataset, batch_size, num_workers, drop_last, shuffle=True)
 
 
 def reader_em_score(model, dataloader, topk_retrievals, tokenizer):
-    """train_e2eqa.py:216-283: greedy answers, exact match against every reference answer, de-duplicated over ranks by query uid."""
-    from emdr2_amd.model.search_strategy import SampleOrGreedySearch
+    """train_e2eqa.py:216-283: greedy (--beam-size 1) or beam-search answers, exact match against every reference answer, de-duplicated
+    over ranks by query uid."""
+    from emdr2_amd.model.search_strategy import BeamSearch, SampleOrGreedySearch
     args = get_args()
-    if args.beam_size != 1:
-        raise NotImplementedError("--beam-size > 1 (BeamSearch) is not built; every shipped script evaluates with --beam-size 1")
+    if args.beam_size < 1:
+        raise AssertionError("--beam-size < 1 is not supported for ORQA reader.")
     score_list, quid_list = [], []
     model.eval()
     with torch.no_grad():
         for batch in dataloader:
             query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, _, _, _, reference = process_batch(batch)
-            search = SampleOrGreedySearch(max_decode_len=args.max_decode_len, bos_id=tokenizer.bos_token_id, eos_id=tokenizer.eos_token_id,
-                                          sample=False, topk_evidence=topk_retrievals)
+            if args.beam_size == 1:
+                search = SampleOrGreedySearch(max_decode_len=args.max_decode_len, bos_id=tokenizer.bos_token_id, eos_id=tokenizer.eos_token_id,
+                                              sample=False, topk_evidence=topk_retrievals)
+            else:
+                search = BeamSearch(max_decode_len=args.max_decode_len, bos_id=tokenizer.bos_token_id, eos_id=tokenizer.eos_token_id,
+                                    beam_size=args.beam_size, topk_evidence=topk_retrievals)
             hypothesis = search.generate_output(model, query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len)
             for quid, ref, hyp in zip(query_uid.tolist(), reference, hypothesis):
                 score_list.append(float(metric_max_over_ground_truths(exact_match_score, tokenizer.decode(hyp), ref)))

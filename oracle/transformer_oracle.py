@@ -419,3 +419,76 @@ def greedy_decode(P, cfg, qext_ids, K, max_decode_len, bos_id, eos_id, return_ma
             row = row[:row.index(eos_id)]
         out.append(row if row else [1])
     return (out, torch.stack(margins, 1)) if return_margins else out
+
+
+# ---- beam search (megatron/model/search_strategy.py:124-182 `BeamSearch`; scores :20-41, beam bookkeeping :44-101, final pick :104-121) ---------
+def _length_penalty(n, alpha):
+    """PolynomialNormalization.lp (search_strategy.py:27-28): ((5 + n) / 6) ** alpha."""
+    return pow(5 + n, alpha) / pow(5 + 1, alpha)
+
+
+def beam_decode(P, cfg, qext_ids, K, max_decode_len, bos_id, eos_id, beam, alpha=0.6, return_gaps=False):
+    """Encode once, then grow `beam` hypotheses per question, one token per step (at most max_decode_len steps).
+      step 0      the `beam` best first tokens by log-probability; their scores are the log-probabilities;
+      step t > 0  every live hypothesis proposes its `beam` best continuations with the length-normalised score
+                  (score * lp(n - 1) + logp) / lp(n), n = tokens held incl. [BOS]; a hypothesis that already holds [EOS] proposes itself
+                  once with its score unchanged (and `beam` - 1 fillers at score - 10000), its next token is [EOS] again; the `beam` best
+                  of the beam * beam proposals of a question survive, best first;
+      stop        when every hypothesis holds [EOS], or after max_decode_len steps;
+      answer      the best-scoring hypothesis of a question (the first one on equal scores) without [BOS], cut before its first [EOS]
+                  (it may be empty: unlike the greedy decoder, search_strategy.py:104-121 does not substitute [1]).
+    With return_gaps: per question the smallest distance, over all steps, between the worst surviving proposal and the best rejected one
+    (taken over ALL beam * V continuations, not only the proposed ones) and the final best-vs-second distance -- what a reduced-precision
+    decoder must stay inside to be asked for the same answer.  qext_ids [B*K, S]."""
+    B = qext_ids.shape[0] // K
+    H = cfg["hidden"]
+    with torch.no_grad():
+        enc = t5_encode(P, "language_model", cfg, qext_ids, ~make_attention_mask_3d(qext_ids, qext_ids)).reshape(B, -1, H)
+        unflat = qext_ids.reshape(B, -1)
+
+        def logp_last(y, e, u):
+            d_mask = ~(make_attention_mask_3d(y, y) * make_history_mask_3d(y))
+            lg = t5_decode(P, "language_model", cfg, y, e, d_mask, ~make_attention_mask_3d(y, u))[:, -1, :].float()
+            return torch.log_softmax(lg, dim=1)
+
+        y = torch.full((B, 1), bos_id, dtype=torch.int64)
+        lp0 = logp_last(y, enc, unflat)                                             # [B, V]
+        top = torch.topk(lp0, beam + 1, dim=1)
+        gaps = (top.values[:, beam - 1] - top.values[:, beam]).clone()
+        total = top.values[:, :beam].reshape(-1)                                    # [B * beam], best first
+        outs = torch.cat([torch.full((B * beam, 1), bos_id, dtype=torch.int64), top.indices[:, :beam].reshape(-1, 1)], dim=1)
+        enc, unflat = enc.repeat_interleave(beam, 0), unflat.repeat_interleave(beam, 0)
+        base = (torch.arange(B) * beam)[:, None]
+        for _ in range(1, max_decode_len):
+            if bool((outs == eos_id).any(1).all()):
+                break
+            n = outs.shape[1]
+            lpv = logp_last(outs, enc, unflat)                                      # [B * beam, V]
+            ended = (outs == eos_id).any(1)
+            live_all = (total[:, None] * _length_penalty(n - 1, alpha) + lpv) / _length_penalty(n, alpha)
+            sc, tok = torch.topk(lpv, beam, dim=1)
+            cand = (total[:, None] * _length_penalty(n - 1, alpha) + sc) / _length_penalty(n, alpha)
+            filler = torch.zeros_like(sc); filler[:, 1:] = -10000.0
+            cand = torch.where(ended[:, None], total[:, None] + filler, cand)
+            tok = torch.where(ended[:, None], torch.full_like(tok, eos_id), tok)
+            best, arg = torch.topk(cand.view(B, beam * beam), beam, dim=1)
+            # the rejected proposals' best, over every continuation of every live hypothesis and the single proposal of every ended one
+            full = torch.where(ended[:, None], torch.full_like(live_all, -3.0e38), live_all)
+            full[:, 0] = torch.where(ended, total, full[:, 0])
+            allv = torch.topk(full.view(B, -1), beam + 1, dim=1).values
+            gaps = torch.minimum(gaps, allv[:, beam - 1] - allv[:, beam])
+            parent = (arg // beam + base).reshape(-1)
+            total = best.reshape(-1)
+            outs = torch.cat([outs[parent], tok.view(B, beam * beam).gather(1, arg).reshape(-1, 1)], dim=1)
+        total = total.view(B, beam)
+        pick = torch.argmax(total, dim=1)                                           # first maximum
+        if beam > 1:
+            t2 = torch.topk(total, 2, dim=1).values
+            gaps = torch.minimum(gaps, t2[:, 0] - t2[:, 1])
+    answers = []
+    for q in range(B):
+        row = outs[q * beam + int(pick[q]), 1:].tolist()
+        if eos_id in row:
+            row = row[:row.index(eos_id)]
+        answers.append(row)
+    return (answers, gaps) if return_gaps else answers

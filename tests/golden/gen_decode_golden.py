@@ -1,7 +1,9 @@
 """Generate tests/golden/decode_ref.npz -- greedy answer generation of the REFERENCE (megatron/model/search_strategy.py:185-240,
 `SampleOrGreedySearch(sample=False)`, the decoder of every shipped evaluation) on the toy EMDR2 model of model_ref.npz with its injected
 retriever: 16 questions, decoded token ids, and per step the margin between the best and the second-best logit (the bf16 HIP path can
-only be asked to reproduce an argmax whose margin exceeds its round-off).  Build container only; tensors only."""
+only be asked to reproduce an argmax whose margin exceeds its round-off); and tests/golden/decode_beam_ref.npz -- the reference's
+`BeamSearch` (search_strategy.py:124-182, length-normalised scores of :20-41, beam bookkeeping of :44-101, best-beam pick of :104-121) on
+the same model and questions at beam sizes 2 and 3: the decoded ids.  Build container only; tensors only."""
 import os
 import sys
 
@@ -108,6 +110,26 @@ def main():
                         bos=np.int64(t5_tok.bos_token_id), eos=np.int64(t5_tok.eos_token_id))
     print("decoded", ids.tolist())
     print("min margin per question", np.stack(margins).T.min(1).round(4).tolist())
+
+    # ---- beam search of the reference on the same model and questions ---------------------------------------------------------------
+    from megatron.model.search_strategy import BeamSearch
+    model.forward = orig_forward
+    beams = {}
+    EOS_BIAS = 0.34                       # second variant: an LM-head bias on [EOS] that makes beams END (the flat toy reader never emits it)
+    for tag, eos_bias in (("", 0.0), ("_eos", EOS_BIAS)):
+        with torch.no_grad():
+            model.state_dict()["language_model.lm_head.bias"][t5_tok.eos_token_id] = eos_bias
+        for k in (2, 3):
+            bs = BeamSearch(max_decode_len=d["dec"], bos_id=t5_tok.bos_token_id, eos_id=t5_tok.eos_token_id, beam_size=k, alpha=0.6, topk_evidence=K)
+            with torch.no_grad(), _ref_import.cuda_calls_on_cpu():
+                o = bs.generate_output(model, uid, qb, q_types, q_mask, qb.clone(), q_len)
+            Lb = max(max(len(x) for x in o), 1)
+            a = np.full((NQ, Lb), -1, dtype=np.int64)
+            for i, x in enumerate(o):
+                a[i, :len(x)] = x
+            beams["beam%d%s" % (k, tag)] = a
+            print("beam", k, tag, a.tolist())
+    np.savez_compressed(os.path.join(HERE, "decode_beam_ref.npz"), alpha=np.float64(0.6), eos_bias=np.float64(EOS_BIAS), **beams)
 
 
 if __name__ == "__main__":

@@ -101,3 +101,73 @@ def test_cached_decode_equals_block_decode():
                 break
     assert compared >= 4 * B, compared
     assert sum(x == y for x, y in zip(inc, blk)) >= B // 2                     # and most questions decode identically to the end
+
+
+def _beam(m, qb, k, max_len):
+    from emdr2_amd.model.search_strategy import BeamSearch
+    s = BeamSearch(max_len, BOS, EOS, beam_size=k, alpha=0.6, topk_evidence=KK)
+    uid = -torch.arange(1, B + 1).cuda()
+    return s.generate_output(m, uid, qb.cuda(), torch.zeros_like(qb).cuda(), None, qb.cuda(), (qb != 0).sum(1).cuda())
+
+
+@pytest.mark.parametrize("with_eos", [False, True])
+def test_beam_search_matches_the_oracle_beam_search(with_eos):
+    """BeamSearch on the HIP path (one position per step, self-attention caches re-ordered by parent, encoder K/V expanded once) against the
+    oracle's beam search -- pinned on the reference's BeamSearch outputs by tests/test_oracle_transformer.py -- on the same weights: the
+    same answer for every question whose survivor / rejected and best / second-best score distances exceed bf16 round-off (the toy reader's
+    1,920 proposals per step lie close: most questions have a nearer tie somewhere, and still most decode identically -- a wrong cache
+    re-ordering would leave none).  The [EOS] variant biases the LM head so that hypotheses end at different steps (frozen scores, [EOS]
+    refills, early stop)."""
+    from emdr2_amd.model import kernels as K
+    m, qb, ext = _model_and_inputs()
+    P = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    max_len = 8
+    if with_eos:
+        y = torch.full((B, 1), BOS, dtype=torch.int64)
+        with torch.no_grad():
+            enc = to.t5_encode(P, "language_model", CFG, ext, ~to.make_attention_mask_3d(ext, ext)).reshape(B, -1, CFG["hidden"])
+            lg = to.t5_decode(P, "language_model", CFG, y, enc, ~(to.make_attention_mask_3d(y, y) * to.make_history_mask_3d(y)),
+                              ~to.make_attention_mask_3d(y, ext.reshape(B, -1)))[:, -1, :]
+        bias = float((torch.topk(lg, 2, dim=1).values[:, 1] - lg[:, EOS]).median())      # [EOS] on a par with the runner-up token
+        P["language_model.lm_head.bias"][EOS] += bias
+        with torch.no_grad():
+            m.language_model.lm_head.bias[EOS] += bias
+        K.WEIGHTS.invalidate()
+    early = 0
+    for k in (2, 3):
+        ref, gaps = to.beam_decode(P, CFG, ext, KK, max_len, BOS, EOS, k, 0.6, return_gaps=True)
+        ours = _beam(m, qb, k, max_len)
+        assert len(ours) == B
+        for q in range(B):
+            if float(gaps[q]) > 1.2e-2:                                # log-probability units; the logits are O(0.5), bf16 round-off O(4e-3)
+                assert ours[q] == ref[q], (k, q, ours[q], ref[q], float(gaps[q]))
+            early += ours[q] == ref[q] and len(ref[q]) < max_len
+        assert sum(a == b for a, b in zip(ours, ref)) >= 10, (k, [(a, b, float(g)) for a, b, g in zip(ours, ref, gaps) if a != b])
+    if with_eos:
+        assert 0 < early < 2 * B, early
+    assert _beam(m, qb, 1, max_len) == [a if a != [1] else [] for a in _greedy_cut(m, qb, max_len)]   # beam 1 = greedy (same kernels, same arg-maxes)
+
+
+def _greedy_cut(m, qb, max_len):
+    from emdr2_amd.model.search_strategy import SampleOrGreedySearch
+    s = SampleOrGreedySearch(max_len, BOS, EOS, sample=False, topk_evidence=KK)
+    uid = -torch.arange(1, B + 1).cuda()
+    return s.generate_output(m, uid, qb.cuda(), torch.zeros_like(qb).cuda(), None, qb.cuda(), (qb != 0).sum(1).cuda())
+
+
+def test_sampling_decode_draws_from_the_step_distribution():
+    """sample=True (search_strategy.py:213-218): one multinomial draw per step from the softmax of the step's logits -- reproducible under
+    torch's seed, ids inside the vocabulary, and equal to greedy once the distribution is made one-hot (logits scaled up)."""
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.model.search_strategy import SampleOrGreedySearch
+    m, qb, _ = _model_and_inputs()
+    uid = -torch.arange(1, B + 1).cuda()
+    args = (m, uid, qb.cuda(), torch.zeros_like(qb).cuda(), None, qb.cuda(), (qb != 0).sum(1).cuda())
+    s = SampleOrGreedySearch(8, BOS, EOS, sample=True, topk_evidence=KK)
+    torch.manual_seed(5); a = s.generate_output(*args)
+    torch.manual_seed(5); b = s.generate_output(*args)
+    torch.manual_seed(6); c = s.generate_output(*args)
+    assert a == b and a != c
+    assert all(0 <= t < V for row in a for t in row)
+    greedy = SampleOrGreedySearch(8, BOS, EOS, sample=False, topk_evidence=KK).generate_output(*args)
+    assert a != greedy                                                  # a flat toy distribution: the draws do not follow the arg-max

@@ -145,6 +145,35 @@ def test_greedy_decode_matches_the_reference_search_strategy():
     np.testing.assert_allclose(margins.numpy(), d["margins"], rtol=2e-2, atol=2e-4)
 
 
+def test_beam_decode_matches_the_reference_beam_search():
+    """The oracle's beam search against the ids the reference's own BeamSearch produced (search_strategy.py:124-182) on the toy model of
+    decode_ref.npz, beam sizes 2 and 3, without and with an LM-head bias on [EOS] that makes hypotheses end (tests/golden/decode_beam_ref.npz)."""
+    import os
+    import assembly_cases
+    from oracle import assembly_oracle as ao
+    g, P, _, meta, passages, titles = mf.load()
+    here = os.path.join(os.path.dirname(__file__), "golden")
+    d, b = np.load(os.path.join(here, "decode_ref.npz")), np.load(os.path.join(here, "decode_beam_ref.npz"))
+    P = {k: _sharpen(k, v, float(d["reader_gain"])) for k, v in P.items()}
+    corpus = ao.Corpus(passages, titles, assembly_cases.build()["group_of_doc"])
+    _, _, ext, _, _ = ao.postprocess(d["query_uid"].tolist(), d["query_ids"].tolist(), d["query_len"].tolist(), d["topk_ids"].tolist(), corpus,
+                                     mf.CFG["topk"], mf.CFG["seq_ret"], mf.CFG["seq"], meta["cls"], meta["sep"], meta["pad"])
+    ext = torch.tensor(ext, dtype=torch.int64)
+    ended = 0
+    for tag, eos_bias in (("", 0.0), ("_eos", float(b["eos_bias"]))):
+        P2 = dict(P)
+        P2["language_model.lm_head.bias"] = P["language_model.lm_head.bias"].clone()
+        P2["language_model.lm_head.bias"][int(d["eos"])] = eos_bias
+        for k in (2, 3):
+            outs = to.beam_decode(P2, mf.CFG, ext, mf.CFG["topk"], int(d["max_decode_len"]), int(d["bos"]), int(d["eos"]), k, float(b["alpha"]))
+            ref = [[t for t in row if t >= 0] for row in b["beam%d%s" % (k, tag)].tolist()]
+            assert outs == ref, (tag, k)
+            ended += sum(len(r) < int(d["max_decode_len"]) for r in ref)
+    assert ended >= 4                                                    # the [EOS] variants do end hypotheses early
+    greedy = to.greedy_decode(P, mf.CFG, ext, mf.CFG["topk"], int(d["max_decode_len"]), int(d["bos"]), int(d["eos"]))
+    assert to.beam_decode(P, mf.CFG, ext, mf.CFG["topk"], int(d["max_decode_len"]), int(d["bos"]), int(d["eos"]), 1) == greedy   # beam 1 = greedy
+
+
 def test_bf16_faithful_mode_is_pinned_on_the_fp32_oracle():
     """The bf16-faithful form of the oracle (rounding where the HIP kernels store bf16) against the fp32 form -- itself pinned on the
     reference above -- on the reference fixture: logits / losses / gradients differ by bf16 round-off only, weight gradients stay fp32
