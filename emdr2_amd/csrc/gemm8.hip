@@ -156,6 +156,12 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
             acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV[ks], av[f][ks], acc[2 * (MH) + f][NH], 0, 0, 0)
+// first K-tile of an output tile: each accumulator's first MFMA takes C = 0 as an inline constant, so the accumulators are never cleared by
+// separate instructions (128 v_mov per wave and tile otherwise, paid inside the VALU-bound epilogues)
+#define G8_MFMA_Z(MH, NH, BV)                                                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
+            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV[ks], av[f][ks], ks == 0 ? zero16 : acc[2 * (MH) + f][NH], 0, 0, 0)
 #define G8_SYNC_COMPUTE(MFMAS) G8_SYNC_COMPUTE_W(asm volatile("s_waitcnt vmcnt(8)" ::: "memory"), MFMAS)
 // first K-tile after a tile seam: the epilogue's stores sit in the (in-order) vmcnt queue between the DMA issued before the seam and the
 // DMA issued now.  "All DMA except the newest four half-tiles has landed" is then vmcnt(8 + stores): the write-backs of the previous
@@ -177,12 +183,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     __builtin_amdgcn_sched_barrier(0)
 
     floatx16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
     // ---- XCD stagger.  Every tile takes the same time, so without this all 256 CUs reach their epilogues together and 33 MB of output hits
     // the memory system as one burst per tile period (the store issue then stalls for microseconds).  XCD x starts x/8 of a tile period late:
@@ -201,45 +202,53 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     // stores one wave issues per tile (LSE mode: data-dependent count, no relaxation)
     constexpr int EPI_STORES = (EPI & G8_LSE) ? 0 : ((EPI & G8_PRE) ? 32 : 16);
     for (int ti = 0; ti < my_count; ++ti) {
-        for (int kt2 = 0; kt2 < KT; kt2 += 2) {
-            const bool after_seam = EPI_STORES > 0 && kt2 == 0 && ti > 0;
-            // ---- K-tile in buffer 0
-            G8_READ_B(0, 0, b0v); G8_READ_A(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(2, 1);
-            G8_SYNC_COMPUTE_SEAM(G8_MFMA(0, 0, b0v));
-            G8_BARRIER();
-            G8_READ_B(0, 1, b1v);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(3, 1);
-            G8_SYNC_COMPUTE_SEAM(G8_MFMA(0, 1, b1v));
-            G8_BARRIER();
-            G8_READ_A(0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(0, 0);
-            G8_SYNC_COMPUTE_SEAM(G8_MFMA(1, 1, b1v));
-            G8_BARRIER();
-            G8_STAGE(1, 0);
-            G8_SYNC_COMPUTE_SEAM(G8_MFMA(1, 0, b0v));
-            G8_BARRIER();
-            // ---- K-tile in buffer 1
-            G8_READ_B(1, 0, b0v); G8_READ_A(1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(2, 0);
-            G8_SYNC_COMPUTE(G8_MFMA(0, 0, b0v));
-            G8_BARRIER();
-            G8_READ_B(1, 1, b1v);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(3, 0);
-            G8_SYNC_COMPUTE(G8_MFMA(0, 1, b1v));
-            G8_BARRIER();
-            G8_READ_A(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            G8_STAGE(0, 1);
-            G8_SYNC_COMPUTE(G8_MFMA(1, 1, b1v));
-            G8_BARRIER();
-            G8_STAGE(1, 1);
-            G8_SYNC_COMPUTE(G8_MFMA(1, 0, b0v));
+        // one pair of K-tiles (buffer 0, buffer 1); FIRST: the pair that opens an output tile (zero-C MFMAs, seam form of the DMA waits)
+#define G8_KPAIR(FIRST, MF)                                                                                                               \
+        do {                                                                                                                              \
+            G8_READ_B(0, 0, b0v); G8_READ_A(0, 0);                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(2, 1);                                                                                                               \
+            G8_SYNC_COMPUTE_SEAM(MF(0, 0, b0v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_READ_B(0, 1, b1v);                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(3, 1);                                                                                                               \
+            G8_SYNC_COMPUTE_SEAM(MF(0, 1, b1v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_READ_A(0, 1);                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(0, 0);                                                                                                               \
+            G8_SYNC_COMPUTE_SEAM(MF(1, 1, b1v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_STAGE(1, 0);                                                                                                               \
+            G8_SYNC_COMPUTE_SEAM(MF(1, 0, b0v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_READ_B(1, 0, b0v); G8_READ_A(1, 0);                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(2, 0);                                                                                                               \
+            G8_SYNC_COMPUTE(G8_MFMA(0, 0, b0v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_READ_B(1, 1, b1v);                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(3, 0);                                                                                                               \
+            G8_SYNC_COMPUTE(G8_MFMA(0, 1, b1v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_READ_A(1, 1);                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            G8_STAGE(0, 1);                                                                                                               \
+            G8_SYNC_COMPUTE(G8_MFMA(1, 1, b1v));                                                                                          \
+            G8_BARRIER();                                                                                                                 \
+            G8_STAGE(1, 1);                                                                                                               \
+            G8_SYNC_COMPUTE(G8_MFMA(1, 0, b0v));                                                                                          \
+        } while (0)
+        {
+            const bool after_seam = EPI_STORES > 0 && ti > 0;
+            G8_KPAIR(1, G8_MFMA_Z);
+            if (2 < KT) { G8_BARRIER(); }
+        }
+        for (int kt2 = 2; kt2 < KT; kt2 += 2) {
+            constexpr bool after_seam = false;
+            G8_KPAIR(0, G8_MFMA);
             if (kt2 + 2 < KT) { G8_BARRIER(); }
         }
         // ---- tile seam.  The leading half is past its last MFMAs one barrier interval before the trailing half: it takes the closing barrier of
@@ -261,11 +270,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) {
-                    asm volatile("" ::"v"(acc[mi][ni]));
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-                }
+                for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
             if (wr == 1) { G8_BARRIER(); }
             continue;
         }
@@ -367,10 +372,6 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                 if constexpr (HAS_RES) {
                     if (mi + 2 < 4) load_res(mi + 2, rr[mi & 1]);
                 }
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
             }
         } else {
             // ---- LSE mode: logits = alpha * acc + bias stay in registers.  Per C row (one lane pair e31 / e31+32 holds its 64 columns of this
@@ -394,7 +395,6 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                         x[ni][r] = t;
                         mx = fmaxf(mx, t);
                         if ((long long)n == lab) { gold = t; has = true; }
-                        acc[mi][ni][r] = 0.f;
                     }
                 const float mo = __shfl_xor(mx, 32);
                 mx = fmaxf(mx, mo);

@@ -36,24 +36,30 @@ __device__ __forceinline__ void store_stream(uint16_t *dst, uint4 v)
     __builtin_nontemporal_store(x, (u32x4_t *)dst);
 }
 // erf-form GELU 0.5 x (1 + erf(x / sqrt 2)).  erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, far below the bf16 output grid) on one
-// v_rcp and one v_exp: ~14 VALU ops where the library erff costs ~3x that.
+// v_rcp and one v_exp; the library erff costs ~3x.  With erf(|z|) = 1 - P(t) exp(-z^2), t = 1 / (1 + p |z|), both signs of x collapse into
+//   gelu(x) = max(x, 0) - |x| * (P(t) / 2) * exp(-x^2 / 2)
+// (x >= 0: x - x P e / 2;  x < 0: x P e / 2): 11 full-rate VALU ops (|x| and the negations ride as source modifiers), the 1/2 folded into the
+// polynomial's coefficients, exp(-x^2 / 2) = exp2(-(x sqrt(log2(e) / 2))^2).
+__device__ __forceinline__ float gelu_half_poly_exp(float x, float &e)
+{
+    const float t = __builtin_amdgcn_rcpf(fmaf(fabsf(x), 0.3275911f * 0.70710678118654752f, 1.0f));
+    const float w = x * 0.84932180028801904f;                                      // sqrt(log2(e) / 2)
+    e = __builtin_amdgcn_exp2f(-(w * w));                                          // exp(-x^2 / 2)
+    return t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 0.5f * 1.061405429f, 0.5f * -1.453152027f), 0.5f * 1.421413741f), 0.5f * -0.284496736f), 0.5f * 0.254829592f);
+}
 __device__ __forceinline__ float gelu_erf(float x)
 {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);
-    const float erf_abs = fmaf(-poly, e, 1.0f);
-    return 0.5f * x * (1.0f + copysignf(erf_abs, x));
+    float e;
+    const float hp = gelu_half_poly_exp(x, e);
+    return fmaf(-fabsf(x), hp * e, fmaxf(x, 0.0f));
 }
-// d/dx of the erf-form GELU: Phi(x) + x phi(x), same erf approximation and the same exponential as the forward
+// d/dx of the erf-form GELU: Phi(x) + x phi(x) = step(x) + exp(-x^2 / 2) (x / sqrt(2 pi) - sign(x) P(t) / 2), same erf approximation and
+// the same exponential as the forward
 __device__ __forceinline__ float gelu_erf_grad(float x)
 {
-    const float z = fabsf(x) * 0.70710678118654752f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    const float poly = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);          // exp(-x^2 / 2)
-    const float cdf = 0.5f * (1.0f + copysignf(fmaf(-poly, e, 1.0f), x));
-    return fmaf(x * 0.3989422804014327f, e, cdf);
+    float e;
+    const float hp = gelu_half_poly_exp(x, e);
+    const float step = x >= 0.0f ? 1.0f : 0.0f;
+    return fmaf(e, fmaf(x, 0.3989422804014327f, -copysignf(hp, x)), step);
 }
 #endif

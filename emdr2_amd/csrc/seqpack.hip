@@ -18,24 +18,30 @@ namespace {
 
 #define LAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : -3)
 
-// One workgroup: len[i] by a wave per sequence (ballot over 64-token chunks), then an exclusive scan of the lengths by the whole group.
-// Also emits sum(len^2) (the attention score count of the packed self-attention, for flop accounting) and the longest length (the attention
-// grids are sized by it) next to the total.
-__global__ void __launch_bounds__(1024) seq_lengths_kernel(const long long *ids, int n, int S, int *cu, long long *totals)
+// Two launches.  seq_len_kernel: a wave per sequence (ballot over 64-token chunks), 16 sequences per workgroup, len[i] -> cu[i] (the
+// 13 MB of ids of a 3,200 x 512 block go through the whole chip, not through one CU).  seq_lengths_kernel: ONE workgroup turns the lengths
+// in cu[] into their exclusive scan in place, and emits sum(len^2) (the attention score count of the packed self-attention, for flop
+// accounting) and the longest length (the attention grids are sized by it) next to the total.
+__global__ void __launch_bounds__(1024) seq_len_kernel(const long long *ids, int n, int S, int *cu)
+{
+    const int lane = threadIdx.x & 63, i = blockIdx.x * 16 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    int last = -1;
+    for (int c = 0; c < S; c += 64) {
+        const int pos = c + lane;
+        const unsigned long long w = __builtin_amdgcn_ballot_w64(pos < S && ids[(long long)i * S + (pos < S ? pos : 0)] != 0);
+        if (w) last = c + 63 - __builtin_clzll(w);
+    }
+    if (lane == 0) cu[i] = last < 0 ? S : last + 1;
+}
+
+__global__ void __launch_bounds__(1024) seq_lengths_kernel(int n, int *cu, long long *totals)
 {
     extern __shared__ int len_s[];               // n ints
     __shared__ int part[16], max_part[16];
     __shared__ long long sq_part[16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = wave; i < n; i += 16) {
-        int last = -1;
-        for (int c = 0; c < S; c += 64) {
-            const int pos = c + lane;
-            const unsigned long long w = __builtin_amdgcn_ballot_w64(pos < S && ids[(long long)i * S + (pos < S ? pos : 0)] != 0);
-            if (w) last = c + 63 - __builtin_clzll(w);
-        }
-        if (lane == 0) len_s[i] = last < 0 ? S : last + 1;
-    }
+    for (int i = tid; i < n; i += 1024) len_s[i] = cu[i];
     __syncthreads();
     // scan: thread t owns a contiguous chunk of sequences
     const int per = (n + 1023) / 1024, lo = tid * per, hi = min(n, lo + per);
@@ -114,8 +120,8 @@ extern "C" int emdr2_seq_lengths(const int64_t *ids, int n, int S, int32_t *cu, 
 {
     if (!ids || !cu || !totals || n < 1 || S < 1) return -1;
     if (n > 16000) return -4;                                                    // the lengths live in LDS (64 KB)
-    hipLaunchKernelGGL(seq_lengths_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), (hipStream_t)stream, (const long long *)ids, n, S, (int *)cu,
-                       (long long *)totals);
+    hipLaunchKernelGGL(seq_len_kernel, dim3((unsigned)(n + 15) / 16), dim3(1024), 0, (hipStream_t)stream, (const long long *)ids, n, S, (int *)cu);
+    hipLaunchKernelGGL(seq_lengths_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), (hipStream_t)stream, n, (int *)cu, (long long *)totals);
     return LAUNCH_OK();
 }
 
