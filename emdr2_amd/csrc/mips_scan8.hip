@@ -150,6 +150,12 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
         _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
             acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[f][ks], BV[ks], acc[2 * (MH) + f][NH], 0, 0, 0)
+// first K-tile of a row tile: each accumulator's first MFMA takes C = 0 as an inline constant -- the accumulators are never cleared by
+// separate instructions (128 v_mov per wave and item otherwise, inside the filter's VALU time)
+#define S8_MFMA_Z(MH, NH, BV)                                                                                                             \
+    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
+        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
+            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[f][ks], BV[ks], ks == 0 ? zero16 : acc[2 * (MH) + f][NH], 0, 0, 0)
 #define S8_SYNC_COMPUTE(BETWEEN, MFMAS)                                                                                                   \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
@@ -199,12 +205,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     }
 
     floatx16 acc[4][2];
-#pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 #ifdef EMDR2_EXPERIMENTS
     if (hq == 1) for (int i = 0; i < P.s.tune >> 8; ++i) __builtin_amdgcn_s_sleep(32);      // EMDR2_MIPS_TUNE bits 8..: late start of the second half, 2,048 cycles each
@@ -216,45 +217,50 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     if (wr == 1) { S8_BARRIER(); }
 
     for (int ti = 0; ti < my_count; ++ti) {
-        for (int kt2 = 0; kt2 < KT; kt2 += 2) {
-            // ---- K-tile in buffer 0
-            S8_READ_B(0, 0, b0v); S8_READ_A(0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(2, 1);
-            S8_SYNC_COMPUTE(if (wr == 0 && kt2 == 0 && ti > 0) S8_MAYBE_FLUSH(), S8_MFMA(0, 0, b0v));
-            S8_BARRIER();
-            S8_READ_B(0, 1, b1v);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(3, 1);
-            S8_SYNC_COMPUTE(, S8_MFMA(0, 1, b1v));
-            S8_BARRIER();
-            S8_READ_A(0, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(0, 0);
-            S8_SYNC_COMPUTE(, S8_MFMA(1, 1, b1v));
-            S8_BARRIER();
-            S8_STAGE(1, 0);
-            S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));
-            S8_BARRIER();
-            // ---- K-tile in buffer 1
-            S8_READ_B(1, 0, b0v); S8_READ_A(1, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(2, 0);
-            S8_SYNC_COMPUTE(, S8_MFMA(0, 0, b0v));
-            S8_BARRIER();
-            S8_READ_B(1, 1, b1v);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(3, 0);
-            S8_SYNC_COMPUTE(, S8_MFMA(0, 1, b1v));
-            S8_BARRIER();
-            S8_READ_A(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-            S8_STAGE(0, 1);
-            S8_SYNC_COMPUTE(, S8_MFMA(1, 1, b1v));
-            S8_BARRIER();
-            S8_STAGE(1, 1);
-            S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));
-            S8_COUPLE();
+        // one pair of K-tiles (buffer 0, buffer 1); HOOK runs behind the first barrier, MF is the MFMA form of the first K-tile
+#define S8_KPAIR(HOOK, MF)                                                                                                                \
+        do {                                                                                                                              \
+            S8_READ_B(0, 0, b0v); S8_READ_A(0, 0);                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(2, 1);                                                                                                               \
+            S8_SYNC_COMPUTE(HOOK, MF(0, 0, b0v));                                                                                         \
+            S8_BARRIER();                                                                                                                 \
+            S8_READ_B(0, 1, b1v);                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(3, 1);                                                                                                               \
+            S8_SYNC_COMPUTE(, MF(0, 1, b1v));                                                                                             \
+            S8_BARRIER();                                                                                                                 \
+            S8_READ_A(0, 1);                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(0, 0);                                                                                                               \
+            S8_SYNC_COMPUTE(, MF(1, 1, b1v));                                                                                             \
+            S8_BARRIER();                                                                                                                 \
+            S8_STAGE(1, 0);                                                                                                               \
+            S8_SYNC_COMPUTE(, MF(1, 0, b0v));                                                                                             \
+            S8_BARRIER();                                                                                                                 \
+            S8_READ_B(1, 0, b0v); S8_READ_A(1, 0);                                                                                        \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(2, 0);                                                                                                               \
+            S8_SYNC_COMPUTE(, S8_MFMA(0, 0, b0v));                                                                                        \
+            S8_BARRIER();                                                                                                                 \
+            S8_READ_B(1, 1, b1v);                                                                                                         \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(3, 0);                                                                                                               \
+            S8_SYNC_COMPUTE(, S8_MFMA(0, 1, b1v));                                                                                        \
+            S8_BARRIER();                                                                                                                 \
+            S8_READ_A(1, 1);                                                                                                              \
+            __builtin_amdgcn_sched_barrier(0);                                                                                            \
+            S8_STAGE(0, 1);                                                                                                               \
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 1, b1v));                                                                                        \
+            S8_BARRIER();                                                                                                                 \
+            S8_STAGE(1, 1);                                                                                                               \
+            S8_SYNC_COMPUTE(, S8_MFMA(1, 0, b0v));                                                                                        \
+            S8_COUPLE();                                                                                                                  \
+        } while (0)
+        S8_KPAIR(if (wr == 0 && ti > 0) S8_MAYBE_FLUSH(), S8_MFMA_Z);
+        if (2 < KT) { S8_BARRIER(); }
+        for (int kt2 = 2; kt2 < KT; kt2 += 2) {
+            S8_KPAIR(, S8_MFMA);
             if (kt2 + 2 < KT) { S8_BARRIER(); }
         }
         // ---- item seam.  The leading half is past its last MFMAs one barrier interval before the trailing half: it takes the closing barrier of
@@ -303,10 +309,6 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
                     }
                 }
             }
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
         }
         if (__builtin_amdgcn_ballot_w64(stored)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (wr == 1) {
