@@ -171,7 +171,7 @@ def choose_retention(ctx, world):
     # what the full-recompute step needed, plus the caching allocator's overhead (measured: reserved = 1.08 x allocated at the peak), plus a
     # margin: packed token counts -- and with them every activation size -- move by a fraction of a percent from step to step
     peak = int(torch.cuda.max_memory_allocated() * 1.08)
-    spare = (25 << 30) if not Kmod.PACKING.enabled else (22 << 30)
+    spare = (25 << 30) if not Kmod.PACKING.enabled else (12 << 30)
     budget = max(0, int((capacity - spare - peak) / 1.08))
     hist = [(S, rows) for n, S, rows in Kmod.PACKING.history if n == ctx.B * ctx.K] if Kmod.PACKING.enabled else []
     rows_reader = max([r for S, r in hist if S == ctx.S] + [0]) or ctx.B * ctx.K * ctx.S                 # (the larger of the two S-long stacks: qext)
