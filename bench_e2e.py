@@ -226,15 +226,20 @@ def run(ctx, steps, warmup, world):
         warmup += 1
         # then one more untimed step so the allocator has grown before the timed region; if the estimate was too optimistic on this box the
         # plan is thinned out (context tower first, then half of the reader layers, then the reference's full recompute)
-        for plan in ((keep, sel_r, sel_c), (0, sel_r, 0), (0, sel_r // 2, 0), (0, 0, 0)):
+        # (a plan also counts as too tight when the caching allocator had to give blocks back to the driver and ask again during the trial
+        # step -- `num_alloc_retries` -- : such a step runs, but at 1.2-1.3 x the time)
+        retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
+        for plan in ((keep, sel_r, sel_c), (0, sel_r, max(sel_c - 3, 0)), (0, sel_r, 0), (0, sel_r // 2, 0), (0, 0, 0)):
             keep, sel_r, sel_c = plan
             ctx.model.set_recompute_keep_last(keep)
             ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
             torch.cuda.empty_cache()                         # blocks cached for the previous retention pattern do not fit the new one
+            before = retries()
             try:
                 loss = ctx.step()
                 warmup += 1
-                break
+                if retries() == before or plan == (0, 0, 0):
+                    break
             except torch.cuda.OutOfMemoryError:
                 ctx.opt.zero_grad()
                 import gc
@@ -303,6 +308,7 @@ def run(ctx, steps, warmup, world):
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()), "replica_parameter_checksums": replicas,
                    "reindex_rows_per_step": ctx.reindex, "peak_hbm_gb": round(torch.cuda.max_memory_allocated() / 1e9, 1),
+                   "allocator_retries": int(torch.cuda.memory_stats().get("num_alloc_retries", 0)),       # cached blocks freed and re-requested: > 0 = the plan is too tight
                    "optimizer_launches_per_step": getattr(ctx.opt, "optimizer_launches", None),
                    "gradient_exchange": "bf16 all-reduce of %d flat buckets, %.2f GB per step" % (len(ctx.opt.buckets), sum(b["n"] for b in ctx.opt.buckets) * 2 / 1e9)},
         # dominant kernels of the step: the dense linears (NT GEMM forward / input gradients, TN GEMM weight gradients)

@@ -94,14 +94,19 @@ def weight_grad_nt(dyT, xT):
     return gemm_nt(dyT, M, xT, M, c, Kd, N, Kd, M, split_k=split)
 
 
-def weight_grad_tn(dy, x, colsum=None):
+def weight_grad_tn(dy, x, colsum=None, into=None):
     """dW [N, K] fp32 = dy [M, N]^T @ x [M, K] straight from the row-major activations (gemm_tn.hip); `colsum` (fp32 [N]) accumulates the
-    bias gradient.  Few output tiles, reduction over all tokens -> the reduction is split across the chip."""
+    bias gradient.  Few output tiles, reduction over all tokens -> the reduction is split across the chip.  `into` (fp32 [N, K], holding
+    zeros or earlier contributions): accumulate there with the slices' atomics instead of returning a fresh tensor -- taken only when the
+    reduction is split (a single slice stores plainly); the caller learns which from the returned tensor."""
     M, N = dy.shape
     Kd = x.shape[1]
     tiles = ((N + 255) // 256) * ((Kd + 255) // 256)
     split = max(1, min(512 // max(tiles, 1), M // 4096))
-    c = (torch.zeros if split > 1 else torch.empty)((N, Kd), dtype=torch.float32, device=dy.device)
+    if into is not None and split > 1:
+        c = into
+    else:
+        c = (torch.zeros if split > 1 else torch.empty)((N, Kd), dtype=torch.float32, device=dy.device)
     _native.check(_lib().emdr2_gemm_tn_bf16(dy.data_ptr(), dy.stride(0), x.data_ptr(), x.stride(0), c.data_ptr(), Kd, N, Kd, M, split, _ptr(colsum),
                                             _sp()), "gemm_tn_bf16")
     return c
@@ -190,6 +195,37 @@ def _accum_grad(p, g_f32):
         p.grad = g_f32
     else:
         p.grad += g_f32        # rare (a parameter used twice in one backward): tied embedding / LM head
+
+
+def _grad_buffer(p, shape=None):
+    """Where a kernel that ACCUMULATES (atomics, +=) should put the fp32 gradient of parameter p: the parameter's own slice of the
+    optimizer's flat gradient bucket while that bucket still takes contributions (training.FlatAdam zeroes its buckets once per step: no
+    per-parameter fill, no copy afterwards), else a fresh zeroed tensor.  Returns (buffer, direct)."""
+    if GRAD_SINK is not None and GRAD_SINK.owns(p):
+        v = GRAD_SINK.accumulation_target(p)
+        if v is not None:
+            return v, True
+    return torch.zeros(p.shape if shape is None else shape, dtype=torch.float32, device=p.device), False
+
+
+def _deliver_grad(p, buf, direct):
+    if direct:
+        GRAD_SINK.contributed(p)
+    else:
+        _accum_grad(p, buf)
+
+
+def _linear_grads_into(dy2, x2, weight, bias):
+    """dW = dy^T x and the bias gradient of a linear layer in its checkpoint row order, accumulated where the parameters' gradients live."""
+    db, db_direct = _grad_buffer(bias) if bias is not None else (None, False)
+    tw, tw_direct = _grad_buffer(weight) if GRAD_SINK is not None and GRAD_SINK.owns(weight) else (None, False)
+    dW = weight_grad_tn(dy2, x2, colsum=db, into=tw if tw_direct else None)
+    if tw_direct and dW is tw:
+        GRAD_SINK.contributed(weight)
+    else:
+        _accum_grad(weight, dW)
+    if bias is not None:
+        _deliver_grad(bias, db, db_direct)
 
 
 # ---- packed ("varlen") sequence layout ---------------------------------------------------------------------------------------
@@ -374,17 +410,9 @@ class LinearFn(torch.autograd.Function):
             wt = w_bf16_t(weight) if ctx.row_perm is None else WEIGHTS.get(weight, "perm_t", lambda: transpose(w_bf16_perm(weight, ctx.row_perm)))
             dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                      # [M,N] x [K,N]^T
         if weight.requires_grad:
-            db = torch.zeros(N, dtype=torch.float32, device=dy.device) if bias is not None else None
             if M % 32:
                 raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
-            dW = weight_grad_tn(dy2, x2, colsum=db)                                       # [N, K] fp32 = dy^T x (+ bias gradient), no transposes
-            if ctx.row_perm is not None:                                                  # back to the checkpoint's interleaved row order
-                un = torch.empty_like(dW); un[ctx.row_perm] = dW; dW = un
-                if bias is not None:
-                    ub = torch.empty_like(db); ub[ctx.row_perm] = db; db = ub
-            _accum_grad(weight, dW)
-            if bias is not None:
-                _accum_grad(bias, db)
+            _linear_param_grads(dy2, x2, weight, bias, ctx.row_perm)                      # [N, K] fp32 = dy^T x (+ bias gradient), no transposes
         return dx, None, None, None, dres, None, None, None
 
 
@@ -443,13 +471,9 @@ class MLPFn(torch.autograd.Function):
         # d(pre) = (dy W2) * gelu'(pre): the multiply rides in the GEMM epilogue
         dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
         gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)
-        db2 = torch.zeros(H, dtype=torch.float32, device=dy.device)
-        _accum_grad(w2, weight_grad_tn(dy2, inter, colsum=db2))
-        _accum_grad(b2, db2)
+        _linear_grads_into(dy2, inter, w2, b2)
         dx = matmul_nt(dpre, w_bf16_t(w1)).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
-        db1 = torch.zeros(F, dtype=torch.float32, device=dy.device)
-        _accum_grad(w1, weight_grad_tn(dpre, x2, colsum=db1))
-        _accum_grad(b1, db1)
+        _linear_grads_into(dpre, x2, w1, b1)
         return dx, None, None, None, None, dres, None, None, None
 
 
@@ -484,14 +508,7 @@ class LayerNormFn(torch.autograd.Function):
         rows, H = x2.shape
         dy2 = dy.reshape(rows, H).contiguous()
         dres = dpass.reshape(rows, H).contiguous() if dpass is not None else None
-        dx = torch.empty_like(x2)
-        dg = torch.zeros(H, dtype=torch.float32, device=dy.device)
-        db = torch.zeros_like(dg)
-        _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
-                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
-        _accum_grad(gamma, dg)
-        _accum_grad(beta, db)
-        return dx.reshape(dy.shape), None, None, None, None
+        return _ln_backward(dy2, x2, gamma, beta, mean, rstd, dres).reshape(dy.shape), None, None, None, None
 
 
 def _ln_forward(x2, gamma, beta, eps):
@@ -508,12 +525,11 @@ def _ln_backward(dy2, x2, gamma, beta, mean, rstd, dres):
     """dx of LayerNorm (+ dres, the gradient of a residual branch that by-passed it); accumulates the gain / bias gradients."""
     rows, H = x2.shape
     dx = torch.empty_like(x2)
-    dg = torch.zeros(H, dtype=torch.float32, device=x2.device)
-    db = torch.zeros_like(dg)
+    (dg, dg_direct), (db, db_direct) = _grad_buffer(gamma), _grad_buffer(beta)            # the kernel adds its column sums atomically
     _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
                                              dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
-    _accum_grad(gamma, dg)
-    _accum_grad(beta, db)
+    _deliver_grad(gamma, dg, dg_direct)
+    _deliver_grad(beta, db, db_direct)
     return dx
 
 
@@ -522,12 +538,14 @@ def _linear_param_grads(dy2, x2, weight, bias, row_perm):
     N = weight.shape[0]
     if dy2.shape[0] % 32:
         raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
+    if row_perm is None:
+        _linear_grads_into(dy2, x2, weight, bias)
+        return
     db = torch.zeros(N, dtype=torch.float32, device=dy2.device) if bias is not None else None
     dW = weight_grad_tn(dy2, x2, colsum=db)
-    if row_perm is not None:
-        un = torch.empty_like(dW); un[row_perm] = dW; dW = un
-        if bias is not None:
-            ub = torch.empty_like(db); ub[row_perm] = db; db = ub
+    un = torch.empty_like(dW); un[row_perm] = dW; dW = un
+    if bias is not None:
+        ub = torch.empty_like(db); ub[row_perm] = db; db = ub
     _accum_grad(weight, dW)
     if bias is not None:
         _accum_grad(bias, db)
@@ -632,16 +650,12 @@ class LNMLPFn(torch.autograd.Function):
             gemm_nt(ln, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
         finally:
             RECOMPUTE.active -= 1
-        db2 = torch.zeros(H, dtype=torch.float32, device=dy.device)
-        _accum_grad(w2, weight_grad_tn(dy2, inter, colsum=db2))
-        _accum_grad(b2, db2)
+        _linear_grads_into(dy2, inter, w2, b2)
         del inter
         dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
         gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)         # (dy W2) * gelu'(pre) in the epilogue
         del pre
-        db1 = torch.zeros(F, dtype=torch.float32, device=dy.device)
-        _accum_grad(w1, weight_grad_tn(dpre, ln, colsum=db1))
-        _accum_grad(b1, db1)
+        _linear_grads_into(dpre, ln, w1, b1)
         del ln
         dln = matmul_nt(dpre, w_bf16_t(w1))
         del dpre
@@ -866,8 +880,8 @@ class EmbeddingFn(torch.autograd.Function):
         ids, types, W, P, T, seqs = ctx.ids, ctx.types, ctx.W, ctx.P, ctx.T, ctx.seqs
         H = W.shape[1]
         dout = dout.contiguous()
-        dW, dP = torch.zeros_like(W, dtype=torch.float32), torch.zeros_like(P, dtype=torch.float32)
-        dT = torch.zeros_like(T, dtype=torch.float32) if types is not None else None
+        (dW, dW_direct), (dP, dP_direct) = _grad_buffer(W), _grad_buffer(P)            # the kernels scatter-add their rows atomically
+        dT, dT_direct = _grad_buffer(T) if types is not None else (None, False)
         if seqs is not None:
             _native.check(_lib().emdr2_embedding_packed_bwd(ids.data_ptr(), _ptr(types), seqs.cu.data_ptr(), seqs.n, dout.data_ptr(), dW.data_ptr(),
                                                             dP.data_ptr(), _ptr(dT), seqs.rows, seqs.S, H, T.shape[0] if dT is not None else 0,
@@ -876,10 +890,10 @@ class EmbeddingFn(torch.autograd.Function):
             b, s = ids.shape
             _native.check(_lib().emdr2_embedding_bwd(ids.data_ptr(), _ptr(types), dout.data_ptr(), dW.data_ptr(), dP.data_ptr(), _ptr(dT), b * s, s, H,
                                                      T.shape[0] if dT is not None else 0, float(ctx.drop_p), int(ctx.seed), _sp()), "embedding_bwd")
-        _accum_grad(W, dW)
-        _accum_grad(P, dP)
+        _deliver_grad(W, dW, dW_direct)
+        _deliver_grad(P, dP, dP_direct)
         if dT is not None:
-            _accum_grad(T, dT)
+            _deliver_grad(T, dT, dT_direct)
         return None, None, None, None, None, None, None, None
 
 

@@ -115,6 +115,7 @@ class FlatAdam(object):
                                       "exchange and the optimizer step are HIP kernels)")
         self._gsq = torch.zeros(1, dtype=torch.float32, device=dev)
         self._scratch = torch.zeros(1025, dtype=torch.float32, device=dev)
+        self._stale = False
         self.expected = None                  # {param: contributions per step}, learned in the first step
         self.count = {p: 0 for p in self.params}
         self.launched_early = 0
@@ -188,7 +189,9 @@ class FlatAdam(object):
         kernels.ATTN_STASH.store.clear()      # entries of a forward whose backward never ran must not outlive the step
 
     def begin_step(self):
+        self._stale = False
         for b in self.buckets:
+            b["grad"].zero_()                 # ONE fill per bucket: the producing kernels accumulate straight into their slices (accumulation_target)
             b["handle"], b["launched"] = None, False
             b["pending"] = sum(1 for p in b["params"] if self.expected and self.expected.get(p, 0) > 0)
         for p in self.params:
@@ -199,7 +202,35 @@ class FlatAdam(object):
         b, o, n = self.slot[p]
         return b["grad"][o:o + n].view(p.shape)
 
+    def accumulation_target(self, p):
+        """The parameter's slice of its flat gradient bucket, for a kernel that ADDS its contribution there (weight-gradient GEMM slices,
+        bias / LayerNorm column sums, embedding scatter-adds) -- zeroed with the bucket at the start of the step, so neither a per-parameter
+        fill nor a copy is needed; None once the bucket has left for its all-reduce (the contribution then goes through `accumulate`).
+        The caller reports the finished contribution with `contributed(p)`."""
+        if self._stale:
+            self.begin_step()                 # a backward after step() without zero_grad(): the buckets still hold the last step's sums
+        b, o, n = self.slot[p]
+        return None if b["launched"] else b["grad"][o:o + n].view(p.shape)
+
+    def contributed(self, p):
+        b, o, n = self.slot[p]
+        if p.grad is None:
+            p.grad = self.grad_view(p)
+        self._count_contribution(p, b)
+
+    def _count_contribution(self, p, b):
+        self.count[p] += 1
+        if self.expected is not None:
+            exp = self.expected.get(p, 0)                          # (an unexpected or surplus contribution is simply added; finish() re-learns)
+            if self.count[p] == exp:
+                b["pending"] -= 1
+                if b["pending"] == 0:
+                    self._launch(b)
+                    self.launched_early += 1
+
     def accumulate(self, p, g):
+        if self._stale:
+            self.begin_step()
         b, o, n = self.slot[p]
         if b["launched"]:
             # the contribution pattern changed since it was learned: this bucket has left for its all-reduce.  Collect the late-comer in a
@@ -212,20 +243,9 @@ class FlatAdam(object):
                 p.grad = self.grad_view(p)
             return
         v = self.grad_view(p)
-        if self.count[p] == 0:
-            if g.data_ptr() != v.data_ptr():
-                v.copy_(g.view_as(v))
-            p.grad = v
-        else:
-            v.add_(g.view_as(v))
-        self.count[p] += 1
-        if self.expected is not None:
-            exp = self.expected.get(p, 0)                          # (an unexpected or surplus contribution is simply added; finish() re-learns)
-            if self.count[p] == exp:
-                b["pending"] -= 1
-                if b["pending"] == 0:
-                    self._launch(b)
-                    self.launched_early += 1
+        v.add_(g.view_as(v))                                       # (the slice holds zeros or the step's earlier contributions)
+        p.grad = v
+        self._count_contribution(p, b)
 
     def _launch(self, b):
         b["launched"] = True
@@ -295,6 +315,7 @@ class FlatAdam(object):
         self.launches_last_step += 1 + 2 * len(active) + 2 * len(saved)
         self.optimizer_launches = self.launches_last_step
         self.launches_last_step = 0
+        self._stale = True                    # the gradient buckets are spent: the next contribution starts a new step if zero_grad() does not
         from emdr2_amd.model import kernels
         kernels.WEIGHTS.invalidate()          # drops the derived forms (transposed / row-permuted copies) of every weight ...
         self._stamp_all()                     # ... while the bf16 working copies were just written by the Adam kernel itself
