@@ -214,15 +214,25 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
 #pragma unroll
                         for (int j = 0; j < 8; ++j) v[j] = v[j] * p.alpha + bv[j];
                     }
-                    if (p.C2) {
+                    if (p.gelu == 2) {                                   // activation + its derivative (the derivative goes to C2)
+                        float d[8];
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) v[j] = gelu_erf_with_grad(v[j], d[j]);
                         uint32_t w[4];
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
+                        for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(d[2 * j], d[2 * j + 1]);
                         store_stream((uint16_t *)p.C2 + o, make_uint4(w[0], w[1], w[2], w[3]));
-                    }
-                    if (p.gelu) {
+                    } else {
+                        if (p.C2) {
+                            uint32_t w[4];
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+                            for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
+                            store_stream((uint16_t *)p.C2 + o, make_uint4(w[0], w[1], w[2], w[3]));
+                        }
+                        if (p.gelu) {
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) v[j] = gelu_erf(v[j]);
+                        }
                     }
                     if (p.drop_p > 0.f) {
                         const float ik = emdr2_keep_scale(p.drop_p);
@@ -244,6 +254,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                         for (int j = 0; j < 4; ++j) {
                             const float r0 = bf16_to_f32((uint16_t)(rw[j] & 0xffff)), r1 = bf16_to_f32((uint16_t)(rw[j] >> 16));
                             if (p.rmode == 0) { v[2 * j] += r0; v[2 * j + 1] += r1; }
+                            else if (p.rmode == 2) { v[2 * j] *= r0; v[2 * j + 1] *= r1; }
                             else { v[2 * j] *= gelu_erf_grad(r0); v[2 * j + 1] *= gelu_erf_grad(r1); }
                         }
                     }
@@ -277,13 +288,16 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                 if (m >= p.M) continue;
                 const long long o = coff + (long long)m * p.ldc + n;
                 float v = acc[mi][ni][r] * p.alpha + bias;
-                if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
-                if (p.gelu) v = gelu_erf(v);
+                if (p.gelu == 2) { float d; v = gelu_erf_with_grad(v, d); ((uint16_t *)p.C2)[o] = f32_to_bf16(d); }
+                else {
+                    if (p.C2) ((uint16_t *)p.C2)[o] = f32_to_bf16(v);
+                    if (p.gelu) v = gelu_erf(v);
+                }
                 if (p.drop_p > 0.f) v = emdr2_keep(emdr2_row_hash(p.seed, (unsigned long long)m), (uint32_t)n, emdr2_drop_thr(p.drop_p)) ? v * emdr2_keep_scale(p.drop_p) : 0.f;
                 if (p.R) {
                     const float rv = bf16_to_f32(((const uint16_t *)p.R)[o]);
                     if (!p.out_f32) v = bf16_to_f32(f32_to_bf16(v));          // as above: bf16 before it meets the residual
-                    v = p.rmode == 0 ? v + rv : v * gelu_erf_grad(rv);
+                    v = p.rmode == 0 ? v + rv : (p.rmode == 2 ? v * rv : v * gelu_erf_grad(rv));
                 }
                 if (p.splitk > 1) atomicAdd(&((float *)p.C)[o], v);
                 else if (p.out_f32) ((float *)p.C)[o] = v;
@@ -351,7 +365,7 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     if ((sA1 & 7) || (sB1 & 7) || (sA2 & 7) || (sB2 & 7)) return -1;
     GemmParams p;
     p.A = (const char *)A; p.B = (const char *)B; p.C = (char *)C; p.C2 = (char *)pre_act;
-    if (residual_mode != 0 && residual_mode != 1) return -1;
+    if (residual_mode < 0 || residual_mode > 2 || gelu < 0 || gelu > 2 || (gelu == 2 && !pre_act)) return -1;
     p.bias = bias; p.R = (const char *)residual; p.rmode = residual_mode;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc;
     p.sA1 = sA1; p.sB1 = sB1; p.sC1 = sC1; p.sA2 = sA2; p.sB2 = sB2; p.sC2 = sC2;

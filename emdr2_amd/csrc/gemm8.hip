@@ -36,7 +36,7 @@ struct G8Params {
     char *C, *C2;              // C2: optional pre-activation output (bf16)
     const float *bias;
     const char *R;             // optional residual (bf16, indexed like C)
-    int rmode;                 // 0: + R;  1: * gelu'(R)
+    int rmode;                 // 0: + R;  1: * gelu'(R);  2: * R
     long long lda, ldb, ldc;   // elements
     int M, N, K;
     float alpha;
@@ -77,7 +77,7 @@ __device__ __forceinline__ void tile_coords(const G8Params &p, int pos, int &tm,
 
 // EPI: compile-time epilogue recipe (a runtime-branched epilogue kept so many paths live that the register allocator spilled the residual
 // prefetch and the accumulators).  The dispatcher instantiates the combinations the EMDR2 step uses; anything else falls back to gemm.hip.
-enum { G8_BIAS = 1, G8_GELU = 2, G8_DROP = 4, G8_RADD = 8, G8_RGELU = 16, G8_PRE = 32, G8_LSE = 64 };
+enum { G8_BIAS = 1, G8_GELU = 2, G8_DROP = 4, G8_RADD = 8, G8_RGELU = 16, G8_PRE = 32, G8_LSE = 64, G8_PREG = 128, G8_RMUL = 256 };   // PREG (with PRE): C2 receives gelu' of the pre-activation
 
 template <int EPI>
 __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
@@ -275,7 +275,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
             continue;
         }
 #endif
-        constexpr bool LSE = (EPI & G8_LSE) != 0, HAS_BIAS = (EPI & G8_BIAS) != 0, HAS_RES = (EPI & (G8_RADD | G8_RGELU)) != 0;
+        constexpr bool LSE = (EPI & G8_LSE) != 0, HAS_BIAS = (EPI & G8_BIAS) != 0, HAS_RES = (EPI & (G8_RADD | G8_RGELU | G8_RMUL)) != 0;
+        constexpr bool PREG = (EPI & G8_PREG) != 0;
         if constexpr (!LSE) {
             const float keep_scale = emdr2_keep_scale(p.drop_p);
             const uint32_t thr = emdr2_drop_thr(p.drop_p);
@@ -308,15 +309,26 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
+                float act[PREG ? 2 : 1][16];                      // PREG: the activations wait here while their derivatives go out in pass 0
 #pragma unroll
                 for (int pass = 0; pass < npass; ++pass) {
                     const bool final_pass = pass == npass - 1;
 #pragma unroll
                     for (int ni = 0; ni < 2; ++ni) {
                         float v[16];
+                        if constexpr (PREG) {
+                            if (pass == 0) {
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]);
-                        if (final_pass) {
+                                for (int r = 0; r < 16; ++r) act[ni][r] = gelu_erf_with_grad(fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]), v[r]);
+                            } else {
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) v[r] = act[ni][r];
+                            }
+                        } else {
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]);
+                        }
+                        if (final_pass && !PREG) {
                             if constexpr ((EPI & G8_GELU) != 0) {
 #pragma unroll
                                 for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
@@ -358,6 +370,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                                 float x0 = bf16_to_f32((uint16_t)(w[q] & 0xffff)), x1 = bf16_to_f32((uint16_t)(w[q] >> 16));
                                 const float r0 = bf16_to_f32((uint16_t)(rw[q] & 0xffff)), r1 = bf16_to_f32((uint16_t)(rw[q] >> 16));
                                 if constexpr ((EPI & G8_RADD) != 0) { x0 += r0; x1 += r1; }
+                                else if constexpr ((EPI & G8_RMUL) != 0) { x0 *= r0; x1 *= r1; }
                                 else { x0 *= gelu_erf_grad(r0); x1 *= gelu_erf_grad(r1); }
                                 w[q] = pack2_bf16(x0, x1);
                             }
@@ -501,8 +514,8 @@ int emdr2_gemm8_try(const void *A, int64_t lda, const void *B, int64_t ldb, void
     p.A = (const char *)A; p.B = (const char *)B; p.C = (char *)C; p.C2 = (char *)pre_act;
     p.bias = bias; p.R = (const char *)residual; p.rmode = residual_mode;
     p.lda = lda; p.ldb = ldb; p.ldc = ldc; p.M = M; p.N = N; p.K = K; p.alpha = alpha; p.gelu = gelu; p.drop_p = drop_p; p.seed = seed;
-    const int epi = (bias ? G8_BIAS : 0) | (gelu ? G8_GELU : 0) | (drop_p > 0.f ? G8_DROP : 0) | (residual ? (residual_mode == 0 ? G8_RADD : G8_RGELU) : 0) |
-                    (pre_act ? G8_PRE : 0);
+    const int epi = (bias ? G8_BIAS : 0) | (gelu ? G8_GELU : 0) | (drop_p > 0.f ? G8_DROP : 0) |
+                    (residual ? (residual_mode == 0 ? G8_RADD : residual_mode == 2 ? G8_RMUL : G8_RGELU) : 0) | (pre_act ? G8_PRE : 0) | (gelu == 2 ? G8_PREG : 0);
     switch (epi) {
     case 0: return g8_launch<0>(p, stream);                                            // plain (input gradients)
     case G8_BIAS: return g8_launch<G8_BIAS>(p, stream);                                 // QKV / Q / KV projections
@@ -511,6 +524,8 @@ int emdr2_gemm8_try(const void *A, int64_t lda, const void *B, int64_t ldb, void
     case G8_BIAS | G8_RADD: return g8_launch<G8_BIAS | G8_RADD>(p, stream);             // attention output / FFN 4h -> h, evaluation
     case G8_BIAS | G8_DROP | G8_RADD: return g8_launch<G8_BIAS | G8_DROP | G8_RADD>(p, stream);   // the same in training: bias-dropout-add
     case G8_RGELU: return g8_launch<G8_RGELU>(p, stream);                               // d(pre-activation) = (dy W2) * gelu'(pre)
+    case G8_BIAS | G8_GELU | G8_PRE | G8_PREG: return g8_launch<G8_BIAS | G8_GELU | G8_PRE | G8_PREG>(p, stream);   // FFN h -> 4h, derivative kept
+    case G8_RMUL: return g8_launch<G8_RMUL>(p, stream);                                 // d(pre-activation) = (dy W2) * saved gelu'
     default: return -4;
     }
 }

@@ -53,6 +53,14 @@ __device__ __forceinline__ float gelu_erf(float x)
     const float hp = gelu_half_poly_exp(x, e);
     return fmaf(-fabsf(x), hp * e, fmaxf(x, 0.0f));
 }
+// both at once (one rcp, one exp2, one polynomial): the activation and its derivative of the same pre-activation
+__device__ __forceinline__ float gelu_erf_with_grad(float x, float &grad)
+{
+    float e;
+    const float hp = gelu_half_poly_exp(x, e);
+    grad = fmaf(e, fmaf(x, 0.3989422804014327f, -copysignf(hp, x)), x >= 0.0f ? 1.0f : 0.0f);
+    return fmaf(-fabsf(x), hp * e, fmaxf(x, 0.0f));
+}
 // d/dx of the erf-form GELU: Phi(x) + x phi(x) = step(x) + exp(-x^2 / 2) (x / sqrt(2 pi) - sign(x) P(t) / 2), same erf approximation and
 // the same exponential as the forward
 __device__ __forceinline__ float gelu_erf_grad(float x)

@@ -434,14 +434,16 @@ class MLPFn(torch.autograd.Function):
             raise ValueError("MLP input must be contiguous")
         M, H = x2.shape
         F = w1.shape[0]
-        # the pre-activation is only needed by a backward that will really run from THIS forward: not in no-grad passes (the one-context
+        # gelu'(pre-activation) -- all the backward ever needs of the pre-activation, written by the FFN-1 GEMM's epilogue next to the
+        # activation (gelu = 2) and multiplied in by the epilogue of the GEMM that produces d(activation) (residual_mode = 2) -- is only needed
+        # by a backward that will really run from THIS forward: not in no-grad passes (the one-context
         # pass, evaluation) and not in the first run of a checkpointed layer, whose saved tensors are dropped and rebuilt by the re-run
         # (`grad_on` is the caller's grad mode: inside Function.forward grad is always off, and needs_input_grad reflects requires_grad of
         # the parameters even under torch.no_grad())
         need_pre = grad_on and any(ctx.needs_input_grad) and ATTN_STASH.mode != 'store'
         pre = torch.empty((M, F), dtype=BF16, device=x.device) if need_pre else None
         inter = torch.empty((M, F), dtype=BF16, device=x.device)
-        gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
+        gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=2 if need_pre else 1, pre_act=pre)
         y = torch.empty((M, H), dtype=BF16, device=x.device)
         gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=residual.reshape(M, H), drop_p=drop_p, seed=seed)
         # (a placeholder keeps the NUMBER of saved tensors equal between a checkpointed layer's first run and its re-run, which is how
@@ -468,9 +470,9 @@ class MLPFn(torch.autograd.Function):
             dmask = torch.empty_like(dy2)
             _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), H, ctx.drop_p, ctx.seed, _sp()), "dropout")
             dy2 = dmask
-        # d(pre) = (dy W2) * gelu'(pre): the multiply rides in the GEMM epilogue
+        # d(pre) = (dy W2) * gelu'(pre): the multiply rides in the GEMM epilogue (`pre` holds the derivative, see forward)
         dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
-        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)
+        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=2)
         _linear_grads_into(dy2, inter, w2, b2)
         dx = matmul_nt(dpre, w_bf16_t(w1)).reshape(ctx.shp) if ctx.needs_input_grad[0] else None
         _linear_grads_into(dpre, x2, w1, b1)
@@ -647,13 +649,13 @@ class LNMLPFn(torch.autograd.Function):
             ln, _, _ = _ln_forward(x2, gamma, beta, ctx.eps)
             pre = torch.empty((M, F), dtype=BF16, device=dy.device)
             inter = torch.empty((M, F), dtype=BF16, device=dy.device)
-            gemm_nt(ln, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=True, pre_act=pre)
+            gemm_nt(ln, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=2, pre_act=pre)        # pre <- gelu'(pre-activation)
         finally:
             RECOMPUTE.active -= 1
         _linear_grads_into(dy2, inter, w2, b2)
         del inter
         dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
-        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=1)         # (dy W2) * gelu'(pre) in the epilogue
+        gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=2)         # (dy W2) * gelu'(pre) in the epilogue
         del pre
         _linear_grads_into(dpre, ln, w1, b1)
         del ln

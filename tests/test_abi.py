@@ -83,7 +83,8 @@ def test_ops_entry_points_validate_arguments_without_a_gpu(lib):
     assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 40, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 1, 0.0, 0, None) == -1
     assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 2, 0.0, 0, None) == -1
     assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 2, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 0, 0, 1, 0.1, 7, None) == -1
-    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 2, 0, 1, 0.0, 0, None) == -1
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 0, None, None, 3, 0, 1, 0.0, 0, None) == -1      # residual_mode is 0, 1 or 2
+    assert lib.emdr2_gemm_nt_bf16(one, 64, one, 64, one, 64, 16, 16, 64, 1, 0, 0, 0, 1, 0, 0, 0, 1.0, None, 2, None, None, 0, 0, 1, 0.0, 0, None) == -1      # gelu = 2 needs pre_act
     assert lib.emdr2_gemm_tn_bf16(one, 64, one, 64, one, 64, 64, 64, 48, 1, None, None) == -1      # R % 32
     assert lib.emdr2_gemm_tn_bf16(None, 64, one, 64, one, 64, 64, 64, 64, 1, None, None) == -1
     # attention: head dim 64 and sk % 32 == 0 only (-4 = unsupported shape, the caller falls back to the composed path)

@@ -83,6 +83,18 @@ def test_gemm8_epilogues():
     x = R.float()
     gelu_grad = 0.5 * (1 + torch.erf(x / 2 ** 0.5)) + x * torch.exp(-0.5 * x * x) / (2 * torch.pi) ** 0.5
     assert torch.allclose(_gemm(A, B, residual=R, rmode=1).float(), acc * gelu_grad, rtol=2e-2, atol=3e-2)
+    # the pair the fused MLP runs: gelu = 2 writes gelu'(pre-activation) next to the activation, residual_mode = 2 multiplies it back in
+    C3, der = _gemm(A, B, bias=bias, gelu=2, want_pre=True)
+    assert torch.equal(C3, C)
+    der_ref = 0.5 * (1 + torch.erf(pre_ref / 2 ** 0.5)) + pre_ref * torch.exp(-0.5 * pre_ref * pre_ref) / (2 * torch.pi) ** 0.5
+    assert torch.allclose(der.float(), der_ref, rtol=1e-2, atol=6e-3)
+    assert torch.allclose(_gemm(A, B, residual=R, rmode=2).float(), acc * R.float(), rtol=2e-2, atol=3e-2)
+    # ... on the general kernel too (a shape the persistent one does not take)
+    As, Rs = A[:1000].contiguous(), R[:1000].contiguous()
+    Cs, ders = _gemm(As, B, bias=bias, gelu=2, want_pre=True)
+    assert torch.allclose(Cs.float(), torch.nn.functional.gelu(pre_ref[:1000]), rtol=2e-2, atol=2e-2)
+    assert torch.allclose(ders.float(), der_ref[:1000], rtol=1e-2, atol=6e-3)
+    assert torch.allclose(_gemm(As, B, residual=Rs, rmode=2).float(), acc[:1000] * Rs.float(), rtol=2e-2, atol=3e-2)
 
 
 def test_gemm8_bias_dropout_add_uses_the_shared_mask():
