@@ -296,8 +296,11 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                     if constexpr (HAS_BIAS) t = *(const float4 *)(p.bias + n_w + ni * 32 + 8 * j + 4 * ehi);
                     bcol[ni][4 * j] = t.x; bcol[ni][4 * j + 1] = t.y; bcol[ni][4 * j + 2] = t.z; bcol[ni][4 * j + 3] = t.w;
                 }
-            // residual rows in row order, two 32-row slabs ahead of their use (the main loop's operand registers are free now)
-            uint4 rr[2][4];
+            // residual rows in row order, fetched as far ahead as the registers allow: a slab is staged in ~0.7 us, a residual row takes 1-2 us
+            // to arrive -- two slabs ahead (r02) every slab still waited for its rows.  All four at once where 64 registers are free (the
+            // main loop's operand registers are, the dropout recipe's hash temporaries leave room for three)
+            constexpr int RAHEAD = (EPI & G8_DROP) ? 3 : 4;
+            uint4 rr[RAHEAD][4];
             auto load_res = [&](int mi, uint4(&dst)[4]) {
 #pragma unroll
                 for (int ps = 0; ps < 4; ++ps) {
@@ -305,7 +308,10 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                     dst[ps] = make_uint4(t.x, t.y, t.z, t.w);
                 }
             };
-            if constexpr (HAS_RES) { load_res(0, rr[0]); load_res(1, rr[1]); }
+            if constexpr (HAS_RES) {
+#pragma unroll
+                for (int a = 0; a < RAHEAD; ++a) load_res(a, rr[a]);
+            }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
                 const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
@@ -364,7 +370,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                         const uint2 hi2 = *(const uint2 *)(stg + row * 128 + (((2 * pc16 + 1) ^ (row & 15)) << 3));
                         uint32_t w[4] = {lo.x, lo.y, hi2.x, hi2.y};
                         if (HAS_RES && final_pass) {
-                            const uint32_t rw[4] = {rr[mi & 1][ps].x, rr[mi & 1][ps].y, rr[mi & 1][ps].z, rr[mi & 1][ps].w};
+                            const uint32_t rw[4] = {rr[mi % RAHEAD][ps].x, rr[mi % RAHEAD][ps].y, rr[mi % RAHEAD][ps].z, rr[mi % RAHEAD][ps].w};
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
                                 float x0 = bf16_to_f32((uint16_t)(w[q] & 0xffff)), x1 = bf16_to_f32((uint16_t)(w[q] >> 16));
@@ -383,7 +389,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                     asm volatile("" ::: "memory");                       // (the next pass's writes queue behind these reads in the same in-order LDS pipe)
                 }
                 if constexpr (HAS_RES) {
-                    if (mi + 2 < 4) load_res(mi + 2, rr[mi & 1]);
+                    if (mi + RAHEAD < 4) load_res(mi + RAHEAD, rr[mi % RAHEAD]);
                 }
             }
         } else {

@@ -22,6 +22,7 @@ for epi in epis:
     if "gelu" in epi.split("+"): kw["gelu"] = True
     if "preg" in epi.split("+"): kw.update(gelu=2, pre_act=torch.empty_like(c))        # bias+gelu+preg: gelu' of the pre-activation as the second output
     if epi == "rmul": kw.update(residual=r, residual_mode=2)
+    if epi == "rmul0": kw.update(residual=torch.zeros_like(r), residual_mode=2)                  # (all-zero residual: same traffic, fewer bit flips)
     if "res" in epi.split("+"): kw["residual"] = r
     if "drop" in epi: kw.update(drop_p=0.1, seed=7)
     if epi == "gelu'": kw.update(residual=r, residual_mode=1)
