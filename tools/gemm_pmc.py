@@ -23,7 +23,7 @@ M_FULL = 3200 * 512
 LAUNCHES = 3
 # (kind, M, N, K, epilogue)
 CONFIGS = [("nt", M_FULL, N, K, e) for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))
-           for e in ("plain", "bias", "bias+gelu", "bias+gelu+pre", "bias+res", "bias+drop+res", "gelu'")] + \
+           for e in ("plain", "bias", "bias+gelu", "bias+gelu+pre", "bias+gelu+gelu'out", "bias+res", "bias+drop+res", "gelu'", "x gelu'saved")] + \
           [("tn", M_FULL, N, K, "colsum") for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))]
 
 
@@ -53,6 +53,8 @@ def run():
                 if "res" in epi.split("+"): kw["residual"] = r
                 if "drop" in epi: kw.update(drop_p=0.1, seed=7)
                 if epi == "gelu'": kw.update(residual=r, residual_mode=1)
+                if "gelu'out" in epi.split("+"): kw.update(gelu=2, pre_act=r)     # gelu' of the pre-activation as the second output
+                if epi == "x gelu'saved": kw.update(residual=r, residual_mode=2)
                 K.gemm_nt(a, Kd, b, Kd, c, N, M, N, Kd, **kw)
         torch.cuda.synchronize()
 
@@ -90,8 +92,8 @@ def summarize(dirs, shapes_json, out):
         # algorithmic bytes, reads and writes apart: operands (+ the residual / saved pre-activation the epilogue reads) in, outputs out
         if cfg["kind"] == "nt":
             rd = 2.0 * (cfg["M"] * cfg["K"] + cfg["N"] * cfg["K"])
-            wr = 2.0 * cfg["M"] * cfg["N"] * (2 if "pre" in cfg["epilogue"].split("+") else 1)
-            if "res" in cfg["epilogue"].split("+") or cfg["epilogue"] == "gelu'":
+            wr = 2.0 * cfg["M"] * cfg["N"] * (2 if ("pre" in cfg["epilogue"].split("+") or "gelu'out" in cfg["epilogue"].split("+")) else 1)
+            if "res" in cfg["epilogue"].split("+") or cfg["epilogue"] in ("gelu'", "x gelu'saved"):
                 rd += 2.0 * cfg["M"] * cfg["N"]
         else:
             rd, wr = 2.0 * cfg["M"] * (cfg["N"] + cfg["K"]), 4.0 * cfg["N"] * cfg["K"]
@@ -131,8 +133,8 @@ def summarize(dirs, shapes_json, out):
             if c is None or r.get("batch", 1) != 1:
                 continue
             if r["kind"] == "nt":
-                rd = 2.0 * (r["M"] * r["K"] + r["N"] * r["K"]) + (2.0 * r["M"] * r["N"] if ("res" in epi.split("+") or epi == "gelu'") else 0.0)
-                wr = 2.0 * r["M"] * r["N"] * (2 if "pre" in epi.split("+") else 1)
+                rd = 2.0 * (r["M"] * r["K"] + r["N"] * r["K"]) + (2.0 * r["M"] * r["N"] if ("res" in epi.split("+") or epi in ("gelu'", "x gelu'saved")) else 0.0)
+                wr = 2.0 * r["M"] * r["N"] * (2 if ("pre" in epi.split("+") or "gelu'out" in epi.split("+")) else 1)
             else:
                 rd, wr = 2.0 * r["M"] * (r["N"] + r["K"]), 4.0 * r["N"] * r["K"]
             n = r["launches"]

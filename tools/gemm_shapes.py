@@ -50,8 +50,9 @@ def main():
 
     def gemm_nt(A, lda, B, ldb, C, ldc, M, N, Kd, batch1=1, sA1=0, sB1=0, sC1=0, batch2=1, sA2=0, sB2=0, sC2=0, alpha=1.0, bias=None, gelu=False,
                 pre_act=None, residual=None, split_k=1, drop_p=0.0, seed=0, residual_mode=0):
-        epi = "+".join(n for n, on in (("bias", bias is not None), ("gelu", gelu), ("pre", pre_act is not None), ("drop", drop_p > 0),
-                                      ("res", residual is not None and residual_mode == 0), ("gelu'", residual is not None and residual_mode == 1),
+        epi = "+".join(n for n, on in (("bias", bias is not None), ("gelu", gelu), ("pre", pre_act is not None and gelu != 2), ("gelu'out", gelu == 2),
+                                      ("drop", drop_p > 0), ("res", residual is not None and residual_mode == 0),
+                                      ("gelu'", residual is not None and residual_mode == 1), ("x gelu'saved", residual is not None and residual_mode == 2),
                                       ("f32out", C.dtype == torch.float32), ("splitk%d" % split_k, split_k > 1)) if on) or "plain"
         nb = batch1 * batch2
         g8 = nb == 1 and split_k == 1 and C.dtype != torch.float32 and M % 256 == 0 and N % 256 == 0 and Kd % 128 == 0 and M >= 4096
@@ -59,11 +60,11 @@ def main():
         return timed(key, 2.0 * M * N * Kd * nb, lambda: nt_raw(A, lda, B, ldb, C, ldc, M, N, Kd, batch1, sA1, sB1, sC1, batch2, sA2, sB2, sC2, alpha, bias,
                                                               gelu, pre_act, residual, split_k, drop_p, seed, residual_mode))
 
-    def weight_grad_tn(dy, x, colsum=None):
+    def weight_grad_tn(dy, x, colsum=None, into=None):
         M, N = dy.shape
         Kd = x.shape[1]
         key = ("tn", M, N, Kd, 1, "colsum" if colsum is not None else "plain", "gemm8t_kernel" if M % 64 == 0 else "gemm_tn_kernel")
-        return timed(key, 2.0 * M * N * Kd, lambda: tn_raw(dy, x, colsum))
+        return timed(key, 2.0 * M * N * Kd, lambda: tn_raw(dy, x, colsum, into=into))
 
     def lm_head_gold_logprob(hidden, weight, bias, labels):
         V, H = weight.shape
