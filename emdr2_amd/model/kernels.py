@@ -183,7 +183,7 @@ def w_bf16_perm(p, perm):
     return WEIGHTS.get(p, "perm", lambda: w_bf16(p)[perm].contiguous())
 
 
-GRAD_SINK = None    # a training.GradientBuckets when data-parallel gradient averaging is overlapped with the backward
+GRAD_SINK = None    # the training.FlatAdam that owns the parameters' flat gradient buckets (and overlaps their all-reduce with the backward)
 
 
 def _accum_grad(p, g_f32):
@@ -218,9 +218,9 @@ def _deliver_grad(p, buf, direct):
 def _linear_grads_into(dy2, x2, weight, bias):
     """dW = dy^T x and the bias gradient of a linear layer in its checkpoint row order, accumulated where the parameters' gradients live."""
     db, db_direct = _grad_buffer(bias) if bias is not None else (None, False)
-    tw, tw_direct = _grad_buffer(weight) if GRAD_SINK is not None and GRAD_SINK.owns(weight) else (None, False)
-    dW = weight_grad_tn(dy2, x2, colsum=db, into=tw if tw_direct else None)
-    if tw_direct and dW is tw:
+    tw = GRAD_SINK.accumulation_target(weight) if GRAD_SINK is not None and GRAD_SINK.owns(weight) else None
+    dW = weight_grad_tn(dy2, x2, colsum=db, into=tw)
+    if tw is not None and dW is tw:                               # (a single-slice reduction stores plainly into a tensor of its own)
         GRAD_SINK.contributed(weight)
     else:
         _accum_grad(weight, dW)
