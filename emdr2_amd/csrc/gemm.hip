@@ -390,9 +390,17 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     // EMDR2_GEMM_TILE=22: 128 x 256 tiles on 4 waves, two workgroups per CU (one's epilogue overlaps the other's MFMA loop).  Measured
     // 5-8 % SLOWER than 256 x 256 on the step's linears (1.5x the L2->LDS operand traffic per flop), kept for experiments only.
     if (tile_env == 22 && split_k == 1) return launch_gemm<2, 2>(p, batch, (hipStream_t)stream);
+    if (tile_env == 21 && split_k == 1) return launch_gemm<2, 1>(p, batch, (hipStream_t)stream);
     // EMDR2_GEMM_TILE=44: 256 x 256 tile on FOUR waves of 128 x 128 (256 accumulator registers per lane, one wave per SIMD): 8 fragment
     // reads per 16 MFMAs instead of 6 per 8 -> a third less LDS read traffic per flop
     if (tile_env == 44 && split_k == 1) return launch_gemm<2, 2, 4>(p, batch, (hipStream_t)stream);
 #endif
+    // few output tiles (the decoder's 2,048-row batches, decoding): a 256 x 256 tile per workgroup would leave most of the 256 CUs idle and
+    // every workgroup with the whole K loop to itself -- 128 x 256 tiles (4 waves) while they still make ~128 workgroups, else 128 x 128
+    // (2 waves).  M = 2,048: N = K = 768 26 -> 17 us, K = 3,072 77 -> 46 us, N = 3,072 29 -> 22 us.
+    if (split_k == 1) {
+        const long long t256 = (long long)batch * ((M + 255) / 256) * ((N + 255) / 256), t128 = (long long)batch * ((M + 127) / 128) * ((N + 255) / 256);
+        if (t256 < 192) return t128 >= 128 ? launch_gemm<2, 2>(p, batch, (hipStream_t)stream) : launch_gemm<2, 1>(p, batch, (hipStream_t)stream);
+    }
     return launch_gemm<4, 2>(p, batch, (hipStream_t)stream);
 }
