@@ -1,6 +1,6 @@
 """Traffic summary of the MIPS scan's last row segment from rocprofv3 --pmc passes over tools/scan_launches.py (GPU box):
   tools/pmc_pass.sh scan8 "FETCH_SIZE" "WRITE_SIZE" -- python $PWD/tools/scan_launches.py 21015324 512
-  python tools/mips_pmc_summary.py gpurun_out/pmc_scan8_p1 gpurun_out/pmc_scan8_p2 --out profiles/r02_mips_summary.json
+  python tools/mips_pmc_summary.py gpurun_out/pmc_scan8_p1 gpurun_out/pmc_scan8_p2 --out profiles/r03_mips_summary.json
 Per search the biggest scan launch is the last row segment; FETCH_SIZE (KB) is doubled as MI355X_MICROARCH.md prescribes for 16-byte streaming
 reads on gfx950; bench.py reads `traffic_bytes` from the summary."""
 import csv, glob, json, os, sys
