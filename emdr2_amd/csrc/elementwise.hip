@@ -7,6 +7,19 @@
 namespace {
 
 __device__ __forceinline__ float bf2f(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+typedef uint32_t ew_u32x4 __attribute__((ext_vector_type(4)));
+// row streams that are touched once per launch (LayerNorm inputs / outputs: 2 GB each at the reader's shape): keep them out of the way of
+// what the neighbouring GEMMs want to find in L2
+__device__ __forceinline__ uint4 ld_stream(const uint16_t *p)
+{
+    const ew_u32x4 t = __builtin_nontemporal_load((const ew_u32x4 *)p);
+    return make_uint4(t.x, t.y, t.z, t.w);
+}
+__device__ __forceinline__ void st_stream(uint16_t *p, uint4 v)
+{
+    const ew_u32x4 t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, (ew_u32x4 *)p);
+}
 __device__ __forceinline__ uint16_t f2bf(float f)
 {
     uint32_t u = __float_as_uint(f);
@@ -108,7 +121,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd768_kernel(const uint16_t *x
     const uint16_t *xr = x + (live ? row : rows - 1) * 768;
     uint4 v[3];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) v[i] = *(const uint4 *)(xr + (i * 32 + l31) * 8);
+    for (int i = 0; i < 3; ++i) v[i] = ld_stream(xr + (i * 32 + l31) * 8);
     float f[3][8], s = 0.f, ss = 0.f;
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
@@ -139,7 +152,7 @@ __global__ void __launch_bounds__(256) layernorm_fwd768_kernel(const uint16_t *x
         for (int j = 0; j < 4; ++j)
             o[j] = (uint32_t)f2bf(fmaf((f[i][2 * j] - mu) * rs, gm[2 * j], bt[2 * j])) |
                    ((uint32_t)f2bf(fmaf((f[i][2 * j + 1] - mu) * rs, gm[2 * j + 1], bt[2 * j + 1])) << 16);
-        *(uint4 *)(yr + c) = make_uint4(o[0], o[1], o[2], o[3]);
+        st_stream(yr + c, make_uint4(o[0], o[1], o[2], o[3]));
     }
 }
 
@@ -211,10 +224,10 @@ __global__ void __launch_bounds__(256) layernorm_bwd768_kernel(const uint16_t *d
         const uint16_t *xr = x + row * 768, *dr = dy + row * 768;
         uint4 xv[3], dv[3], rv[3];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) { xv[i] = *(const uint4 *)(xr + (i * 32 + l31) * 8); dv[i] = *(const uint4 *)(dr + (i * 32 + l31) * 8); }
+        for (int i = 0; i < 3; ++i) { xv[i] = ld_stream(xr + (i * 32 + l31) * 8); dv[i] = ld_stream(dr + (i * 32 + l31) * 8); }
         if (dres) {
 #pragma unroll
-            for (int i = 0; i < 3; ++i) rv[i] = *(const uint4 *)(dres + row * 768 + (i * 32 + l31) * 8);
+            for (int i = 0; i < 3; ++i) rv[i] = ld_stream(dres + row * 768 + (i * 32 + l31) * 8);
         }
         const float mu = mean[row], rs = rstd[row];
         float xh[3][8], g[3][8], s1 = 0.f, s2 = 0.f;
@@ -245,7 +258,7 @@ __global__ void __launch_bounds__(256) layernorm_bwd768_kernel(const uint16_t *d
                 if (dres) { a += bf2f((uint16_t)(rw[j] & 0xffff)); b += bf2f((uint16_t)(rw[j] >> 16)); }
                 o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
             }
-            *(uint4 *)(xo + (i * 32 + l31) * 8) = make_uint4(o[0], o[1], o[2], o[3]);
+            st_stream(xo + (i * 32 + l31) * 8, make_uint4(o[0], o[1], o[2], o[3]));
         }
     }
     // both half-waves own the same columns: fold, then reduce the 4 waves through LDS

@@ -2,6 +2,9 @@
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+from emdr2_amd import _native
+if "--exp" in sys.argv:                                     # the other build of the library (A/B)
+    _native.LIB_PATH = _native.LIB_PATH.replace("libemdr2_hip.so", "libemdr2_hip_exp.so")
 from emdr2_amd.model import kernels as K
 g = torch.Generator(device="cuda").manual_seed(0)
 H = 768
