@@ -527,6 +527,7 @@ int emdr2_gemm8_try(const void *A, int64_t lda, const void *B, int64_t ldb, void
     case G8_BIAS: return g8_launch<G8_BIAS>(p, stream);                                 // QKV / Q / KV projections
     case G8_BIAS | G8_GELU: return g8_launch<G8_BIAS | G8_GELU>(p, stream);             // FFN h -> 4h, no backward to follow
     case G8_BIAS | G8_GELU | G8_PRE: return g8_launch<G8_BIAS | G8_GELU | G8_PRE>(p, stream);
+    case G8_RADD: return g8_launch<G8_RADD>(p, stream);                                 // data gradient added onto a running sum (C may be R: kernels.FanInFn)
     case G8_BIAS | G8_RADD: return g8_launch<G8_BIAS | G8_RADD>(p, stream);             // attention output / FFN 4h -> h, evaluation
     case G8_BIAS | G8_DROP | G8_RADD: return g8_launch<G8_BIAS | G8_DROP | G8_RADD>(p, stream);   // the same in training: bias-dropout-add
     case G8_RGELU: return g8_launch<G8_RGELU>(p, stream);                               // d(pre-activation) = (dy W2) * gelu'(pre)

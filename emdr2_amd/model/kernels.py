@@ -228,6 +228,42 @@ def _linear_grads_into(dy2, x2, weight, bias):
         _deliver_grad(bias, db, db_direct)
 
 
+# ---- one input, many linear consumers: the input gradient is summed by the consumers' own GEMMs --------------------------------
+class _FanInState(object):
+    def __init__(self):
+        self.acc = None
+
+
+FANIN = {}      # data_ptr of a tensor that went through `fan_in` -> its gradient accumulator (lives from that forward to its backward)
+
+
+class FanInFn(torch.autograd.Function):
+    """y = x for a tensor that feeds MANY linear layers (the FiD reader's encoder output: the K/V projection of every decoder layer reads all
+    K * S encoder tokens).  Autograd would materialise each consumer's [tokens, h] input gradient and sum them pairwise (11 additions of
+    2 GB tensors per step); instead the consumers' data-gradient GEMMs add their product onto ONE buffer in their epilogue
+    (`LinearFn.backward`, + residual in place) and hand autograd nothing; this node delivers the buffer.  Same roundings as the pairwise
+    bf16 sums (each product is rounded to bf16 before it meets the running sum, csrc/gemm8.hip), same order."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.key = x.data_ptr()
+        FANIN[ctx.key] = _FanInState()
+        ctx.set_materialize_grads(False)
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        st = FANIN.pop(ctx.key, None)
+        acc = st.acc if st is not None else None
+        if g is not None:                                         # a consumer that is not one of ours
+            acc = g if acc is None else acc + g.reshape(acc.shape)
+        return acc
+
+
+def fan_in(x):
+    return FanInFn.apply(x) if torch.is_grad_enabled() and x.requires_grad else x
+
+
 # ---- packed ("varlen") sequence layout ---------------------------------------------------------------------------------------
 class _Packing(object):
     """Switch for the packed layout of the encoder stacks (csrc/seqpack.hip): ON = the context tower, the reader encoder and the
@@ -408,7 +444,14 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = w_bf16_t(weight) if ctx.row_perm is None else WEIGHTS.get(weight, "perm_t", lambda: transpose(w_bf16_perm(weight, ctx.row_perm)))
-            dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                      # [M,N] x [K,N]^T
+            shared = FANIN.get(x2.data_ptr())
+            if shared is None:
+                dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                  # [M,N] x [K,N]^T
+            elif shared.acc is None:
+                shared.acc = matmul_nt(dy2, wt).reshape(ctx.shp)                          # first consumer of a fanned-in input (FanInFn) ...
+            else:
+                acc2 = shared.acc.reshape(M, K)                                           # ... the others add onto it in their epilogue, in place
+                gemm_nt(dy2, N, wt, N, acc2, K, M, K, N, residual=acc2)
         if weight.requires_grad:
             if M % 32:
                 raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")

@@ -224,6 +224,8 @@ class ParallelTransformer(torch.nn.Module):
         self.selective = 0
 
     def forward(self, x, ids, causal=False, encoder_output=None, enc_ids=None):
+        if encoder_output is not None:
+            encoder_output = K.fan_in(encoder_output)             # every layer's K/V projection reads it: one gradient buffer, no pairwise sums
         n_layers = len(self.layers)
         n_keep = min(int(self.keep_last), n_layers)
         n_sel = min(int(self.selective), n_layers - n_keep) if encoder_output is None and not causal else 0

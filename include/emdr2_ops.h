@@ -24,7 +24,8 @@ extern "C" {
  * pre_act (optional, bf16, indexed like C): value before GELU, kept for the backward.  gelu == 2 (needs pre_act): GELU as with 1, but
  * pre_act receives gelu'(value before GELU) instead -- the only thing the backward ever does with the pre-activation, computed here
  * from the fp32 value and next to the activation's own exponential (residual_mode 2 consumes it).
- * residual_mode 0: + residual.  1: the `residual` buffer holds a saved GELU pre-activation u and the result is MULTIPLIED by gelu'(u) --
+ * residual_mode 0: + residual (`residual` may be C itself: every element is read before it is written, by the same lane -- a data gradient
+ * added onto a running sum in place).  1: the `residual` buffer holds a saved GELU pre-activation u and the result is MULTIPLIED by gelu'(u) --
  * the backward of bias-GELU fused into the GEMM that produces d(activation) (saves one 3 x [tokens, ffn] elementwise pass).
  * 2: the result is MULTIPLIED by residual[m, n] (a gelu' saved by gelu == 2: the same backward without the erf arithmetic).
  * split_k > 1: the reduction is cut into split_k slices accumulated with fp32 atomics into a PRE-ZEROED fp32 C (weight
