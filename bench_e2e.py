@@ -127,16 +127,33 @@ def setup(args, rank, world, index=None, topk=50):
         return dict(uid=-torch.arange(1, B + 1, device="cuda"), q=q, types=torch.zeros_like(q), qlen=qlen.to(torch.int64), dec=dec,
                     labels=labels, mask=(labels != 0).float())
 
+    plan = {"keep": 0, "reader": 0, "context": 0, "thinned": 0}         # the retention plan in force (run() fills it in)
+
     def step():
-        try:
-            return step_once()
-        except torch.cuda.OutOfMemoryError:                               # allocator fragmentation: give the blocks back and run the step again
-            import gc
-            opt.zero_grad()
-            gc.collect()
-            torch.cuda.empty_cache()
-            oom_retries[0] += 1
-            return step_once()
+        import gc
+        for attempt in range(6):
+            try:
+                return step_once()
+            except torch.cuda.OutOfMemoryError:
+                opt.zero_grad()
+                gc.collect()
+                torch.cuda.empty_cache()                                  # first: allocator fragmentation -- give the blocks back, same step again
+                oom_retries[0] += 1
+                if attempt >= 1:
+                    # it really does not fit any more: the packed stacks' (sticky) row capacities grow by 16,384-row steps while new maxima
+                    # of real tokens keep arriving (the first tens of steps), and every retained tensor grows with them.  Retain less.
+                    if plan["context"] > 0:
+                        plan["context"] = max(0, plan["context"] - 3)
+                    elif plan["keep"] > 0:
+                        plan["keep"] -= 1
+                    elif plan["reader"] > 0:
+                        plan["reader"] = max(0, plan["reader"] - 2)
+                    else:
+                        raise
+                    plan["thinned"] += 1
+                    model.set_recompute_keep_last(plan["keep"])
+                    model.set_selective_retention(plan["reader"], plan["context"], args.layers if plan["context"] else 0)
+        return step_once()
 
     oom_retries = [0]
 
@@ -153,7 +170,7 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(plan=plan, oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
@@ -246,6 +263,7 @@ def run(ctx, steps, warmup, world):
                 gc.collect()
         fence()
     ctx.keep_last, ctx.selective, ctx.full_recompute_ms = keep, (sel_r, sel_c), (full_ms if keep + sel_r + sel_c > 0 else None)
+    ctx.plan.update(keep=keep, reader=sel_r, context=sel_c)
     from emdr2_amd.model import kernels as Kmod
     alloc_retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
     timed_reruns = 0
@@ -299,6 +317,7 @@ def run(ctx, steps, warmup, world):
                             "with another access shape for which the x 2 is uncalibrated, so their ratios -- and this aggregate -- are upper bounds) and "
                             "WRITE_SIZE; operand-only kernels: 1.16 (N = K = 768), 1.34 (K = 3072), 2.4 - 3.8 (N = 2304 / 3072: B panels re-fetched once "
                             "per round and XCD, DESIGN.md 11)" % (sw["covered_ms"], sw["all_ms"]))
+    ctx.keep_last, ctx.selective = ctx.plan["keep"], (ctx.plan["reader"], ctx.plan["context"])       # (thinned if a step ran out of memory)
     fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)
     sps = steps / elapsed
     gemm_ms, gemm_fl = ms[0] + ms[1], fl[0] + fl[1]
@@ -320,7 +339,7 @@ def run(ctx, steps, warmup, world):
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
                                            ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
                                             "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),
-                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.oom_retries[0],
+                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.oom_retries[0], "retention_thinned_after_out_of_memory": ctx.plan["thinned"],
                    "timed_region_reruns_after_allocator_retry": timed_reruns,
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()), "replica_parameter_checksums": replicas,

@@ -30,6 +30,11 @@ def get_parser():
     g.add_argument('--recompute-keep-last-layers', type=int, default=0,
                    help='(not in the reference) with --checkpoint-activations: keep the activations of the last N reader-encoder layers '
                         'instead of re-running them in the backward (~33 GB of HBM per layer at batch 64 x top-k 50 x 512 tokens)')
+    g.add_argument('--selective-retention-layers', type=str, default='0,0,0',
+                   help='(not in the reference) with --checkpoint-activations: READER,CONTEXT,QUERY encoder layers that keep 6 of their ~16 '
+                        '[tokens, h] activation tensors and rebuild the rest (both LayerNorm outputs, the FFN pre-activation and GELU output) in '
+                        'the backward, instead of being re-run whole (+6.3 GB per reader-encoder layer, +3.0 GB per context-tower layer at '
+                        'batch 64 x top-k 50; packed row counts keep growing by 16,384-row steps over the first tens of steps: leave ~25 GB free)')
     g.add_argument('--seed', type=int, default=1234)
     g.add_argument('--init-method-std', type=float, default=0.02)
     g.add_argument('--lr', type=float, default=None)

@@ -66,6 +66,9 @@ def model_provider(args=None, bert_tokenizer=None, t5_tokenizer=None, arena=None
                        no_query_embedder_training=args.no_query_embedder_training,
                        no_context_embedder_training=args.no_context_embedder_training)
     model.set_recompute_keep_last(getattr(args, "recompute_keep_last_layers", 0))
+    sel = [int(v) for v in str(getattr(args, "selective_retention_layers", "0,0,0")).split(",")]
+    if any(sel):
+        model.set_selective_retention(*(sel + [0, 0, 0])[:3])
     return model
 
 
