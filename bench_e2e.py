@@ -143,7 +143,7 @@ def setup(args, rank, world, index=None, topk=50):
                     # it really does not fit any more: the packed stacks' (sticky) row capacities grow by 16,384-row steps while new maxima
                     # of real tokens keep arriving (the first tens of steps), and every retained tensor grows with them.  Retain less.
                     if plan["context"] > 0:
-                        plan["context"] = max(0, plan["context"] - 3)
+                        plan["context"] = max(0, plan["context"] - 2)
                     elif plan["keep"] > 0:
                         plan["keep"] -= 1
                     elif plan["reader"] > 0:
