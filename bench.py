@@ -103,9 +103,8 @@ def cpu_baseline(args, queries_cpu):
 
 def main():
     args = parse()
-    if int(os.environ.get("WORLD_SIZE", "1")) == 1 and args.gpus > 1:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d for --gpus %d" % (args.gpus, args.gpus))
     from emdr2_amd import dist_util
+    dist_util.self_launch(args.gpus)      # plain `python bench.py --gpus N`: becomes N ranks under torch.distributed.run (no-op inside a launcher)
     # one process per GPU over RCCL; a collective whose peers are gone times out (e2e budget + slack) instead of hanging the launcher
     rank, world, _ = dist_util.init_distributed(timeout_s=args.e2e_timeout + 60.0)
 

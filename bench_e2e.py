@@ -92,7 +92,7 @@ def setup(args, rank, world, index=None, topk=50):
     arena = EvidenceArena.synthetic(args.rows)
     retr = PreComputedEvidenceDocsRetriever.__new__(PreComputedEvidenceDocsRetriever)
     retr.args = types.SimpleNamespace(topk_retrievals=K, seq_length=S, seq_length_ret=S_ret)
-    retr.topk, retr.mips_index, retr.arena, retr.process_group = K, index, arena, None
+    retr.topk, retr.mips_index, retr.arena, retr.process_group, retr.searches = K, index, arena, None, 0
 
     torch.manual_seed(1234)
     cfg = Config(num_layers=args.layers, hidden_size=H, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512, init_method_std=0.02,
@@ -130,40 +130,56 @@ def setup(args, rank, world, index=None, topk=50):
     plan = {"keep": 0, "reader": 0, "context": 0, "thinned": 0}         # the retention plan in force (run() fills it in)
 
     def step():
+        """One training step; a step that runs out of HBM is given up ON ALL RANKS TOGETHER and run again: the rank that failed
+        completes the step's gradient collectives through FlatAdam.abort_step(), its peers learn of it in finish() (StepAborted), and since
+        `attempt` and the plan are then the same everywhere, every rank frees / thins in the same way and re-enters the same collectives."""
         import gc
+        from emdr2_amd.training import StepAborted
         for attempt in range(6):
+            searched = retr.searches
             try:
                 return step_once()
             except torch.cuda.OutOfMemoryError:
-                opt.zero_grad()
-                gc.collect()
-                torch.cuda.empty_cache()                                  # first: allocator fragmentation -- give the blocks back, same step again
-                oom_retries[0] += 1
-                if attempt >= 1:
-                    # it really does not fit any more: the packed stacks' (sticky) row capacities grow by 16,384-row steps while new maxima
-                    # of real tokens keep arriving (the first tens of steps), and every retained tensor grows with them.  Retain less.
-                    if plan["context"] > 0:
-                        plan["context"] = max(0, plan["context"] - 2)
-                    elif plan["keep"] > 0:
-                        plan["keep"] -= 1
-                    elif plan["reader"] > 0:
-                        plan["reader"] = max(0, plan["reader"] - 2)
-                    else:
-                        raise
-                    plan["thinned"] += 1
-                    model.set_recompute_keep_last(plan["keep"])
-                    model.set_selective_retention(plan["reader"], plan["context"], args.layers if plan["context"] else 0)
+                if world > 1 and retr.searches == searched:
+                    raise                                                 # before the forward's own all-gathers completed: peers cannot be told
+                opt.abort_step()
+            except StepAborted:
+                pass
+            opt.zero_grad()
+            gc.collect()
+            torch.cuda.empty_cache()                                      # first: allocator fragmentation -- give the blocks back, same step again
+            oom_retries[0] += 1
+            if attempt >= 1:
+                # it really does not fit any more: the packed stacks' (sticky) row capacities grow by 16,384-row steps while new maxima
+                # of real tokens keep arriving (the first tens of steps), and every retained tensor grows with them.  Retain less.
+                if plan["context"] > 0:
+                    plan["context"] = max(0, plan["context"] - 2)
+                elif plan["keep"] > 0:
+                    plan["keep"] -= 1
+                elif plan["reader"] > 0:
+                    plan["reader"] = max(0, plan["reader"] - 2)
+                else:
+                    raise torch.cuda.OutOfMemoryError("the step does not fit with the reference's full per-layer recompute either")
+                plan["thinned"] += 1
+                model.set_recompute_keep_last(plan["keep"])
+                model.set_selective_retention(plan["reader"], plan["context"], args.layers if plan["context"] else 0)
         return step_once()
 
     oom_retries = [0]
 
+    inject = tuple(int(v) for v in os.environ.get("EMDR2_BENCH_INJECT_OOM", "-1,-1").split(","))    # "rank,call": dry-run hook of the tests
+    calls = [0]
+
     def step_once():
+        calls[0] += 1
         if indexer is not None:
             indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
         opt.zero_grad()
         lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
         loss, stats = emdr2_loss(lm, tlp, one, bt["labels"], bt["mask"], eos_id=30523)
+        if inject == (rank, calls[0]):
+            raise torch.cuda.OutOfMemoryError("injected by EMDR2_BENCH_INJECT_OOM (tests/test_dist_gpu.py)")
         loss.backward()
         opt.finish()                                                      # waits for the bucket all-reduces launched from inside the backward
         opt.step(lr=sched.get_lr())
@@ -245,25 +261,29 @@ def run(ctx, steps, warmup, world):
         # plan is thinned out (context tower first, then half of the reader layers, then the reference's full recompute)
         # (a plan also counts as too tight when the caching allocator had to give blocks back to the driver and ask again during the trial
         # step -- `num_alloc_retries` -- : such a step runs, but at 1.2-1.3 x the time)
-        retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
+        retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0)) + ctx.oom_retries[0]
+
+        def any_rank(flag):                                  # every rank takes the same branch below
+            if world == 1:
+                return bool(flag)
+            t = torch.tensor([int(bool(flag))], device="cuda")
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+            return bool(int(t.item()))
         for plan in ((keep, sel_r, sel_c), (0, sel_r, max(sel_c - 3, 0)), (0, sel_r, 0), (0, sel_r // 2, 0), (0, 0, 0)):
             keep, sel_r, sel_c = plan
+            ctx.plan.update(keep=keep, reader=sel_r, context=sel_c)
             ctx.model.set_recompute_keep_last(keep)
             ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
             torch.cuda.empty_cache()                         # blocks cached for the previous retention pattern do not fit the new one
             before = retries()
-            try:
-                loss = ctx.step()
-                warmup += 1
-                if retries() == before or plan == (0, 0, 0):
-                    break
-            except torch.cuda.OutOfMemoryError:
-                ctx.opt.zero_grad()
-                import gc
-                gc.collect()
+            loss = ctx.step()                                # (an allocation failure inside is handled there, by all ranks together, and counted)
+            warmup += 1
+            if not any_rank(retries() != before) or plan == (0, 0, 0):
+                break
+            keep, sel_r, sel_c = ctx.plan["keep"], ctx.plan["reader"], ctx.plan["context"]     # (the step may have thinned the plan itself)
+        keep, sel_r, sel_c = ctx.plan["keep"], ctx.plan["reader"], ctx.plan["context"]
         fence()
     ctx.keep_last, ctx.selective, ctx.full_recompute_ms = keep, (sel_r, sel_c), (full_ms if keep + sel_r + sel_c > 0 else None)
-    ctx.plan.update(keep=keep, reader=sel_r, context=sel_c)
     from emdr2_amd.model import kernels as Kmod
     alloc_retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0))
     timed_reruns = 0
@@ -329,8 +349,6 @@ def run(ctx, steps, warmup, world):
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
                    "packed_sequences": bool(Kmod.PACKING.enabled),
-                   "dense_layout_ab": "same box, same commit, --no-packing: 2,900 ms/step against 1,941 packed (both with the r02 keep-last policy; "
-                                      "profiles/r03_e2e_dense_layout.json, r03_e2e_packed_first.json); rerun with `bench_e2e.py --no-packing`",
                    # encoder-stack tokens per step (query tower, context tower, reader encoder, one-context pass): real = what the packed
                    # layout runs, padded = the reference's [batch, S] grids
                    "tokens_real": (Kmod.PACKING.real_tokens // steps) if Kmod.PACKING.enabled else None,
@@ -353,10 +371,13 @@ def run(ctx, steps, warmup, world):
                      "per_step": {k: {"ms": ms[i] / steps, "tflops": (fl[i] / (ms[i] * 1e-3) / 1e12 if ms[i] > 0 else 0.0), "launches": int(nl[i] // steps)}
                                   for i, k in enumerate(kinds)},
                      "executed_tflop_per_step": {"gemm": gemm_fl / steps / 1e12, "attention": (fl[2] + fl[3]) / steps / 1e12},
-                     "whole_step_mfu": {"tflops": fl_step * sps / 1e12, "frac": fl_step * sps / 1e12 / MFMA_PEAK_TFLOPS, "flops_per_step_per_gpu": fl_step,
-                                        "convention": "dense-GEMM flops of the reference's PADDED grids, no recompute (SURVEY 8d): with packed sequences "
-                                                      "this is the rate at which the reference's work is retired, not the rate of executed flops "
-                                                      "(executed_tflop_per_step / ms_per_step gives that)"}},
+                     # EXECUTED dense flops (GEMM + attention launches of the timed steps, recompute included) over the whole step time: the
+                     # fraction of the MFMA peak the step actually sustains
+                     "executed_mfu": {"tflops": (gemm_fl + fl[2] + fl[3]) / elapsed / 1e12, "frac": (gemm_fl + fl[2] + fl[3]) / elapsed / 1e12 / MFMA_PEAK_TFLOPS},
+                     # the rate at which the REFERENCE's work is retired: dense-GEMM flops of its padded [batch, S] grids, no recompute
+                     # (SURVEY 8d's 1,906 TFLOP per step), over the step time -- not an achieved-MFMA fraction when sequences are packed
+                     "padded_work_rate": {"tflops": fl_step * sps / 1e12, "frac_of_peak": fl_step * sps / 1e12 / MFMA_PEAK_TFLOPS,
+                                          "flops_per_step_per_gpu": fl_step}},
     }
 
 
@@ -433,6 +454,7 @@ def main():
         print(json.dumps(cpu_baseline_model(args.cpu_seconds, threads=args.cpu_threads)), flush=True)
         return
     from emdr2_amd import dist_util
+    dist_util.self_launch(args.gpus)      # plain `python bench_e2e.py --gpus N`: becomes N ranks under torch.distributed.run
     rank, world, _ = dist_util.init_distributed()
     ctx = setup(args, rank, world, topk=args.topk)
     res = run(ctx, args.steps, args.warmup, world)

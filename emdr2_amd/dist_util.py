@@ -7,6 +7,9 @@ EMDR2_SINGLE_DEVICE=1: all ranks share cuda:0) execute the same lines as an RCCL
 `device_id` hint that lets RCCL bind its communicator eagerly."""
 import datetime
 import os
+import socket
+import subprocess
+import sys
 
 import torch
 
@@ -22,6 +25,33 @@ def local_device(local_rank=None):
     if os.environ.get("EMDR2_SINGLE_DEVICE"):
         local_rank = 0
     return torch.device("cuda", local_rank)
+
+
+def self_launch(gpus, argv=None):
+    """`python bench.py --gpus N` as typed, without a launcher (the reference's one-line launch is `python -m torch.distributed.launch
+    --nproc_per_node N tasks/run.py ...`, examples/openqa/emdr2_nq.sh:35,106): when no launcher has set WORLD_SIZE (or it says 1) and more
+    than one GPU is asked for, re-run the same command line as N ranks under `torch.distributed.run` -- one process per LOCAL_RANK device,
+    rendezvous on 127.0.0.1 and a free port -- and exit with ITS status: non-zero as soon as any rank fails (the launcher then stops the
+    others) or a collective times out.  Only rank 0 prints, so stdout still carries the ONE JSON line.  Returns when nothing is to do (one
+    GPU, or already inside a launcher's rank)."""
+    if gpus <= 1 or int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        return
+    if not os.environ.get("EMDR2_SINGLE_DEVICE") and torch.cuda.is_available() and torch.cuda.device_count() < gpus:
+        raise SystemExit("--gpus %d but only %d device(s) visible (EMDR2_SINGLE_DEVICE=1 EMDR2_DIST_BACKEND=gloo runs all ranks on cuda:0 as a dry run)"
+                         % (gpus, torch.cuda.device_count()))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "LOCAL_WORLD_SIZE", "GROUP_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")              # the host driver does dmabuf IPC only (RCCL's intra-node transport)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or gpus) // gpus)))
+    argv = list(sys.argv if argv is None else argv)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + argv
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def init_distributed(timeout_s=1800.0, rank=None, world=None, local_rank=None):

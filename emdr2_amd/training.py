@@ -61,6 +61,12 @@ def allreduce_gradients(module, group=None):
         off += n
 
 
+class StepAborted(RuntimeError):
+    """Raised by FlatAdam.finish() on EVERY rank of the data-parallel group when any rank gave the step up (FlatAdam.abort_step(): an
+    allocation failure in its forward / backward): the gradient exchange of the step has been completed consistently -- the same
+    collectives, in the same order, on all ranks -- and its result is to be discarded by all of them together."""
+
+
 class FlatAdam(object):
     """The optimizer step AND the data-parallel gradient exchange over FLAT buckets (the reference: apex FusedAdam through
     amp_C.multi_tensor_apply on fp32 masters, fp16/fp16.py:332-354,420-474; global-norm clip via amp_C.multi_tensor_l2norm, mpu/grads.py:74-127;
@@ -81,7 +87,12 @@ class FlatAdam(object):
     reference's fp16 buffer 11 -- the choice is numerics against wire time, the default follows the reference's 16 bits).
     Which parameters receive how many contributions is learned in the first step; if a later step deviates (a branch of the model switched
     on or off), nothing is lost: a contribution that arrives after its bucket left is collected in a side buffer and all-reduced in
-    `finish()`, and the pattern is re-learned from that step.
+    `finish()`, and the pattern is re-learned from that step.  Ranks agree on this: with world > 1 `finish()` starts with ONE small
+    all-reduce (MAX) of [abort flag, late-buffer flag per bucket], every rank joins the late-buffer all-reduce of a bucket if any rank has
+    one (zeros where it has none), and every rank all-reduces EVERY bucket every step -- the sequence of collectives never depends on what
+    a single rank saw.  `abort_step()` is how a rank that cannot finish its backward (allocation failure) leaves the step without leaving
+    its peers in a collective: it issues the bucket all-reduces it still owes (buckets always leave in index order), raises the abort
+    flag, and every rank's `finish()` raises `StepAborted`.
 
     Parameters that never receive a gradient (the reader's unused token-type table) are left untouched, like apex / torch skip `grad is None`."""
 
@@ -120,6 +131,7 @@ class FlatAdam(object):
         self.count = {p: 0 for p in self.params}
         self.launched_early = 0
         self.launches_last_step = 0
+        self.next_bucket = 0                  # buckets leave in INDEX order, every step, on every rank: the sequence of collectives is static
         self._epoch = 0
         import weakref
         kernels.WEIGHTS.listeners.append(weakref.WeakMethod(self._on_invalidate))
@@ -139,7 +151,7 @@ class FlatAdam(object):
         f32 = lambda: torch.zeros(off, dtype=torch.float32, device=dev)
         b = {"params": ordered, "n": off, "split": split, "master": f32(), "grad": f32(), "m": f32(), "v": f32(),
              "work": torch.zeros(off, dtype=torch.bfloat16, device=dev), "xchg": None, "late": None, "pending": 0, "handle": None,
-             "launched": False}
+             "launched": False, "ready": False, "idx": len(self.buckets)}
         for p, o in zip(ordered, offs):
             n = p.numel()
             b["master"][o:o + n].view(p.shape).copy_(p.data)
@@ -193,11 +205,14 @@ class FlatAdam(object):
         self._stale = False
         for b in self.buckets:
             b["grad"].zero_()                 # ONE fill per bucket: the producing kernels accumulate straight into their slices (accumulation_target)
-            b["handle"], b["launched"] = None, False
+            b["handle"], b["launched"], b["ready"] = None, False, False
+            b["late"] = None
             b["pending"] = sum(1 for p in b["params"] if self.expected and self.expected.get(p, 0) > 0)
+            b["ready"] = bool(self.expected) and b["pending"] == 0      # (nothing expected: it leaves, carrying zeros, when its turn comes)
         for p in self.params:
             self.count[p] = 0
             p.grad = None
+        self.next_bucket = 0
 
     def grad_view(self, p):
         b, o, n = self.slot[p]
@@ -226,8 +241,12 @@ class FlatAdam(object):
             if self.count[p] == exp:
                 b["pending"] -= 1
                 if b["pending"] == 0:
-                    self._launch(b)
-                    self.launched_early += 1
+                    # complete: it leaves as soon as every bucket before it has left (reverse registration order is roughly the order in which
+                    # gradients become final, so this rarely holds a bucket back -- and an aborting rank knows what its peers have issued)
+                    b["ready"] = True
+                    while self.next_bucket < len(self.buckets) and self.buckets[self.next_bucket]["ready"]:
+                        self._launch(self.buckets[self.next_bucket])
+                        self.launched_early += 1
 
     def accumulate(self, p, g):
         if self._stale:
@@ -249,7 +268,9 @@ class FlatAdam(object):
         self._count_contribution(p, b)
 
     def _launch(self, b):
+        assert b["idx"] == self.next_bucket
         b["launched"] = True
+        self.next_bucket += 1
         world = self._world()
         if world > 1 and self.exchange_dtype == "fp32":
             b["grad"].mul_(1.0 / world)                            # pre-divide, then sum (distributed.py:56-58)
@@ -263,9 +284,12 @@ class FlatAdam(object):
             self.launches_last_step += 1
             b["handle"] = torch.distributed.all_reduce(b["xchg"], group=self.group, async_op=True)
 
-    def finish(self):
-        """After loss.backward(): reduce what is left, wait for everything, widen the exchanged gradients back to fp32."""
-        if self.expected is None or any(self.count[p] != self.expected.get(p, 0) for p in self.params):
+    def finish(self, abort=False):
+        """After loss.backward(): reduce what is left, wait for everything, widen the exchanged gradients back to fp32.
+        world > 1: every bucket is all-reduced every step and the ranks first agree (one small MAX all-reduce) on whether the step stands and
+        on which buckets carry late contributions; raises StepAborted on every rank if any rank called abort_step()."""
+        world = self._world()
+        if not abort and (self.expected is None or any(self.count[p] != self.expected.get(p, 0) for p in self.params)):
             if self.expected is not None:
                 self.pattern_changes += 1                          # (every rank runs the same model code: they all see the change in the same step)
             self.expected = dict(self.count)
@@ -273,23 +297,50 @@ class FlatAdam(object):
             for p in idle:                                         # no gradient this step: zero its slice (a previous step may have written it)
                 self.grad_view(p).zero_()
             self.inactive = idle                                   # ... and leave it untouched by the update, like `grad is None` in apex / torch
-        for b in self.buckets:
-            if not b["launched"] and any(self.count[p] for p in b["params"]):
+        # what has not left yet, in index order.  world > 1: EVERY bucket is exchanged (a bucket without gradients carries zeros), so the
+        # collectives of a step are the same on a rank that is aborting as on its peers
+        for b in self.buckets[self.next_bucket:]:
+            if world > 1 or any(self.count[p] for p in b["params"]):
                 self._launch(b)
-        world = self._world()
-        for b in self.buckets:
+            else:
+                self.next_bucket += 1
+        late = [b["late"] is not None for b in self.buckets]
+        aborted = bool(abort)
+        if world > 1:
+            flags = torch.tensor([int(aborted)] + [int(x) for x in late], dtype=torch.int32, device=self.buckets[0]["grad"].device)
+            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            flags = flags.tolist()
+            aborted, late = bool(flags[0]), [bool(x) for x in flags[1:]]
+        for b, has_late in zip(self.buckets, late):
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
-                if self.exchange_dtype == "bf16":
+                if self.exchange_dtype == "bf16" and not aborted:
                     _native.check(_native.lib().emdr2_widen_bf16_to_f32(b["xchg"].data_ptr(), b["grad"].data_ptr(), b["n"], _native.stream_ptr()), "widen")
                     self.launches_last_step += 1
-            if b["late"] is not None:                              # contributions that missed their bucket's all-reduce (pattern change)
+            if has_late:                                           # contributions that missed their bucket's all-reduce (pattern change) on SOME rank
+                if b["late"] is None:
+                    b["late"] = torch.zeros(b["n"], dtype=torch.float32, device=b["grad"].device)
                 if world > 1:
                     b["late"].mul_(1.0 / world)
                     torch.distributed.all_reduce(b["late"], group=self.group)
                 b["grad"].add_(b["late"])
                 b["late"] = None
+        if aborted:
+            self._stale = True                                     # the buckets hold a discarded step: the next contribution starts afresh
+            raise StepAborted("a rank of the data-parallel group gave this step up; its gradients are discarded on all ranks")
+
+    def abort_step(self):
+        """This rank cannot complete the step's backward (allocation failure): complete the step's gradient collectives anyway so that the
+        peers, which are waiting in theirs, and this rank stay in lockstep, and tell them to discard the step (their finish() raises
+        StepAborted).  Single process: nothing to do."""
+        if self._world() == 1:
+            self._stale = True
+            return
+        try:
+            self.finish(abort=True)
+        except StepAborted:
+            pass
 
     # ---- the update ---------------------------------------------------------------------------------------------------------------------
     def step(self, lr=None):

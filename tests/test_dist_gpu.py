@@ -119,24 +119,28 @@ def test_two_rank_data_parallel_training_over_rccl(tmp_path):
         assert torch.equal(a, b)
 
 
-def test_bench_two_ranks_on_the_shared_device_prints_both_halves():
-    """The driver's multi-GPU command, dry: `bench.py --gpus 2` under torch.distributed.run as 2 gloo ranks sharing cuda:0 (EMDR2_SINGLE_DEVICE) at a
-    reduced size.  Everything an RCCL run executes runs here except the transport: process-group bring-up through dist_util (the backend is
-    one string), row-sharded scan + ONE all-gather + merge, data-parallel EMDR2 step with the bf16 bucket exchange, the JSON contract."""
+def _plain_bench(extra_env=None, extra_args=()):
+    """`python bench.py --gpus 2 ...` exactly as the driver types it -- NO launcher around it (bench.py starts its own ranks through
+    dist_util.self_launch) -- as 2 gloo ranks sharing cuda:0 (EMDR2_SINGLE_DEVICE) at a reduced size."""
     import json
     import subprocess
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "2000000", "--e2e-steps", "1", "--e2e-warmup", "1",
-           "--batch", "4", "--layers", "2", "--keep-last-layers", "0", "--no-cpu-baseline"]
+    cmd = [sys.executable, "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "2000000", "--e2e-steps", "1", "--e2e-warmup", "1",
+           "--batch", "4", "--layers", "2", "--keep-last-layers", "0", "--no-cpu-baseline"] + list(extra_args)
     out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
     assert out.returncode == 0, out.stderr.decode()[-3000:]
     lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
     assert len(lines) == 1, lines                                      # ONE JSON line, from rank 0
-    r = json.loads(lines[0])
+    return json.loads(lines[0])
+
+
+def test_plain_bench_command_with_two_gpus_launches_its_own_ranks_and_prints_both_halves():
+    """The driver's multi-GPU command, dry (the reference's one-line launch, examples/openqa/emdr2_nq.sh:35,106).
+    Everything an RCCL run executes runs here except the transport: self-launch, process-group bring-up through dist_util (the backend is
+    one string), row-sharded scan + ONE all-gather + merge, data-parallel EMDR2 step with the bf16 bucket exchange, the JSON contract."""
+    r = _plain_bench()
     assert r["metric"] == "mips_queries_per_sec" and r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
     assert r["config"]["rows_per_rank"] == [1000000, 1000000] and r["config"]["unproven_queries"] == 0
     assert r["config"]["allgather_bytes_per_rank"] == 3 * 512 * 50 * 8 and r["config"]["allgather_plus_merge_ms"] > 0
@@ -147,3 +151,34 @@ def test_bench_two_ranks_on_the_shared_device_prints_both_halves():
     cs = e["config"]["replica_parameter_checksums"]
     assert len(cs) == 2 and cs[0] == cs[1], cs                          # the two replicas hold bit-identical parameters after the steps
     assert e["roofline"]["per_step"]["gemm_nt"]["launches"] > 0
+    assert 0 < e["roofline"]["executed_mfu"]["frac"] < 1 and e["roofline"]["padded_work_rate"]["tflops"] > 0
+
+
+def test_a_rank_running_out_of_memory_mid_step_is_recovered_by_all_ranks_together():
+    """rank 1's second step raises an allocation failure after its forward while rank 0 carries on into the backward and
+    its bucket all-reduces.  Rank 1 completes the step's collectives (FlatAdam.abort_step), both ranks discard the step, run it again, and
+    end with bit-identical replicas; nothing hangs, one re-run is reported."""
+    r = _plain_bench({"EMDR2_BENCH_INJECT_OOM": "1,2"}, ["--selective-layers", "2,0"])
+    e = r["e2e"]
+    assert "error" not in e, e
+    assert e["config"]["steps_rerun_after_out_of_memory"] == 1
+    cs = e["config"]["replica_parameter_checksums"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs
+
+
+def test_plain_bench_e2e_command_with_two_gpus():
+    import json
+    import subprocess
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench_e2e.py", "--gpus", "2", "--steps", "1", "--warmup", "1", "--rows", "500000", "--batch", "4", "--layers", "2",
+           "--keep-last-layers", "0"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=900)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["metric"] == "qa_train_steps_per_sec" and r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
+    cs = r["config"]["replica_parameter_checksums"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs
