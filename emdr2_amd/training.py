@@ -6,12 +6,19 @@ import torch
 from emdr2_amd import _native
 
 
+def _no_weight_decay(name):
+    """megatron/model/utils.py:64-83 walks the modules: every parameter of a LayerNorm and every parameter NAMED `bias` goes without weight
+    decay.  All LayerNorm modules of the EMDR2 model have 'layernorm' in their name; pinned on the reference's own grouping of its
+    EMDR2Model by tests/golden/optim_groups.json."""
+    return name == "bias" or name.endswith(".bias") or "layernorm" in name
+
+
 def get_params_for_weight_decay_optimization(module):
-    """No weight decay on LayerNorm parameters and biases (megatron/model/utils.py:64-83)."""
+    """(decayed group, undecayed group) like the reference's function (megatron/model/utils.py:64-83)."""
     decay, no_decay = [], []
     for name, p in module.named_parameters():
-        (no_decay if (name.endswith(".bias") or "layernorm" in name) else decay).append(p)
-    return [{"params": decay}, {"params": no_decay, "weight_decay": 0.0}]
+        (no_decay if _no_weight_decay(name) else decay).append(p)
+    return {"params": decay}, {"params": no_decay, "weight_decay": 0.0}
 
 
 class AnnealingLR(object):
@@ -104,7 +111,7 @@ class FlatAdam(object):
         self.lr, self.betas, self.eps, self.weight_decay, self.clip_grad, self.group = lr, betas, eps, weight_decay, clip_grad, group
         self.exchange_dtype, self.pattern_changes = exchange_dtype, 0
         self.step_count = 0
-        no_decay = set(id(p) for n, p in module.named_parameters() if (n.endswith(".bias") or "layernorm" in n))      # model/utils.py:64-83
+        no_decay = set(id(p) for n, p in module.named_parameters() if self.is_no_decay(n))      # model/utils.py:64-83
         self.params = [p for p in module.parameters() if p.requires_grad][::-1]
         self.slot = {}
         self.buckets = []
@@ -137,6 +144,8 @@ class FlatAdam(object):
         kernels.WEIGHTS.listeners.append(weakref.WeakMethod(self._on_invalidate))
         self.refresh_working_copies()
         self.begin_step()
+
+    is_no_decay = staticmethod(_no_weight_decay)
 
     # ---- layout ---------------------------------------------------------------------------------------------------------------------
     def _close(self, plist, no_decay):

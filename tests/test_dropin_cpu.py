@@ -115,3 +115,32 @@ def test_data_store_round_trip_and_merge(tmp_path):
     a.save_shard(); b.save_shard()
     with pytest.raises(AssertionError):
         a.merge_shards_and_save()
+
+
+def test_store_files_written_by_the_reference_are_read_and_merged(tmp_path):
+    """F7: tests/golden/store_ref.pkl / store_ref_shard1.pkl were WRITTEN by the reference's OpenRetreivalDataStore.save_shard /
+    merge_shards_and_save (emdr2_index.py:63-100; gen_store_optim_golden.py).  Ours must read the merged file (same ids, same insertion
+    order, rows = fp16 of what went in), merge a reference-written shard with one of its own, and write a file the same bytes decode from."""
+    import pickle
+    import shutil
+    import numpy as np
+    from emdr2_amd.data.emdr2_index import OpenRetreivalDataStore
+    gold = os.path.join(os.path.dirname(__file__), "golden")
+    ref = np.load(os.path.join(gold, "store_ref.npz"))
+    rows16 = ref["rows"].astype(np.float16)
+    path = str(tmp_path / "emb.pkl")
+    shutil.copy(os.path.join(gold, "store_ref.pkl"), path)
+    st = OpenRetreivalDataStore(path, load_from_path=True, rank=0)
+    assert list(st.embed_data) == ref["merged_order"].tolist() == ref["ids"].tolist()
+    for i, doc in enumerate(ref["ids"].tolist()):
+        v = st.embed_data[doc]
+        assert v.dtype == np.float16 and np.array_equal(v.view(np.uint16), rows16[i].view(np.uint16))
+    # our rank 0 + the reference's rank-1 shard file -> the reference's merged store
+    mine = OpenRetreivalDataStore(path, load_from_path=False, rank=0)
+    mine.add_block_data(ref["ids"][:60].tolist(), ref["rows"][:60])
+    mine.save_shard()
+    shutil.copy(os.path.join(gold, "store_ref_shard1.pkl"), os.path.join(mine.temp_dir_name, "1.pkl"))
+    mine.merge_shards_and_save()
+    ours, theirs = pickle.load(open(path, "rb")), pickle.load(open(os.path.join(gold, "store_ref.pkl"), "rb"))
+    assert list(ours) == list(theirs) == ["embed_data"] and list(ours["embed_data"]) == list(theirs["embed_data"])
+    assert all(np.array_equal(ours["embed_data"][k].view(np.uint16), theirs["embed_data"][k].view(np.uint16)) for k in theirs["embed_data"])

@@ -146,3 +146,17 @@ def test_checkpoint_files_carry_version_and_release_checkpoints_restart_the_run(
     open(ck.get_checkpoint_tracker_filename(d), "w").write("40")
     with pytest.raises(ValueError, match="no-load-optim"):
         ck.load_checkpoint(d, object(), BadOpt(), None)
+
+
+def test_weight_decay_predicate_reproduces_the_reference_groups():
+    """F6 (second half): the parameter names of the two optimizer groups the REFERENCE's get_params_for_weight_decay_optimization
+    (megatron/model/utils.py:64-83) forms on its EMDR2Model (tests/golden/optim_groups.json, gen_store_optim_golden.py): our name
+    predicate -- used by get_params_for_weight_decay_optimization AND by FlatAdam's bucket layout -- splits the same names the same way.
+    (tests/test_task_gpu.py builds our EMDR2Model and checks the groups of its actual parameters.)"""
+    import json
+    from emdr2_amd.training import FlatAdam
+    ref = json.load(open(os.path.join(GOLD, "optim_groups.json")))
+    every = sorted(ref["weight_decay"] + ref["no_weight_decay"])
+    assert len(every) == len(set(every)) == 130 and ref["no_weight_decay_value"] == 0.0
+    assert [n for n in every if FlatAdam.is_no_decay(n)] == ref["no_weight_decay"]
+    assert [n for n in every if not FlatAdam.is_no_decay(n)] == ref["weight_decay"]
