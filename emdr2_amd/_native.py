@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")     # tools/ may point this at lib/libemdr2_hip_exp.so (`make exp`) before first use
 
-EMDR2_ABI_VERSION = 1
+EMDR2_ABI_VERSION = 2
 FLAG_AMBIGUOUS = 1
 FLAG_OVERFLOW = 2
 MAX_TOPK = 120

@@ -92,7 +92,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     const bool wave_live = q0 < sq;                 // a wave past the end of its sequence only helps to stage K / V (decoder: sq = 32 of 128)
 
     // LDS-DMA: per block 16 pieces of 1 KiB (8 for K, 8 for V); wave w moves pieces w, w + NW, .. of each: 8 rows x 128 B,
-    // lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row) (tile_swz has period 8 in the row)
+    // lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row) (tile_swz looks at row bits 1..3: period 16, and a wave's pieces are 32 rows apart)
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + (k_off + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
     const char *v_src = p.v + (v_off + (long long)n * p.v_sn) * 2 + pslot * 16;

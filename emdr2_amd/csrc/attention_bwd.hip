@@ -33,13 +33,17 @@ struct BwdParams {
     char *dq, *dk, *dv;
     const long long *ids_q, *ids_k;
     const float *m, *l;
-    float *dstat;                  // D[q] = rowsum(dO o O), [b, heads, sq]
+    float *dstat;                  // per-query statistics the dq kernel leaves for the dk/dv kernel, [4][stat_n] (stat index as m / l):
+                                   //   exp2 offset pm = m log2(e) + log2(l) | D (1 - p), D = rowsum(dO o O) | dropout row hash (bits) | 1 = real token (bits)
+    long long stat_n;              // batch * heads * sq (dense) or heads * total_q (packed)
     long long q_sb, q_ss, q_sn;    // element strides of q (batch, sequence, head); k and v share k_*
     long long k_sb, k_ss, k_sn, v_sb, v_ss, v_sn;
     long long dq_sb, dq_ss, dkv_sb, dkv_ss;   // element strides (batch, sequence) of the gradient outputs; heads are 64 apart
     int heads, sq, sk, causal, batch;
     float scale, drop_p;
     uint32_t seed;
+    float keep_scale, inv_keep_scale, scale2;      // 1 / (1 - p) of the surviving probabilities (and its inverse); scale * log2(e): host-computed -> SGPRs
+    uint32_t drop_thr;
     // packed operands (attention.hip: AttnParams): sequence b owns rows [cu[b], cu[b+1]); statistics [heads, tq] when cu_q is given
     const int *cu_q, *cu_k;
     long long tq;
@@ -73,12 +77,7 @@ __device__ __forceinline__ SeqExtent seq_extent(const BwdParams &p, int b, int n
 // Like the forward (attention.hip): VALU-bound, so workgroups are FOUR waves (128 queries) at <= 168 VGPRs -- three per CU, each on its own
 // barrier -- and a staged 64-key block is consumed as two 32-key steps (one S / dP accumulator pair live); DROP / CAUSAL are compile-time.
 #define BNW 4
-#ifndef DKV_OCC
-#define DKV_OCC 2
-#endif
-#ifndef KNW
 #define KNW 4                  // waves (32 keys each) per workgroup of the dK / dV kernel
-#endif
 template <bool DROP, bool CAUSAL>
 __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams p)
 {
@@ -136,11 +135,10 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
             const auto r_ = __builtin_amdgcn_permlane32_swap(__float_as_uint(acc), __float_as_uint(acc), false, false);
             Dq = __uint_as_float(r_[0]) + __uint_as_float(r_[1]);
         }
-        if (qvalid && hi == 0) p.dstat[si] = Dq;
     }
     const bool qpad = !qvalid || p.ids_q[ex.qrow0 + qc] == 0;
     const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;  // a wave of padded queries: every dS is 0
-    const float sc = p.scale * L2E;
+    const float sc = p.scale2;
     const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
 
     for (int blk = wave; blk < nblk; blk += BNW) {
@@ -157,9 +155,14 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) dqacc[j][r] = 0.f;
-    const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
-    const uint32_t thr = emdr2_drop_thr(p.drop_p);
+    const float ik = DROP ? p.keep_scale : 1.f;
+    const float Dk = DROP ? Dq * p.inv_keep_scale : Dq;
+    const uint32_t thr = p.drop_thr;
     const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)si);
+    if (qvalid && hi == 0) {       // the dk/dv kernel stages these per 32-query step by LDS-DMA: nothing per query is recomputed there
+        p.dstat[si] = pm; p.dstat[p.stat_n + si] = Dk;                          // (the dk/dv kernel works in units of 1 / keep_scale as well)
+        ((uint32_t *)p.dstat)[2 * p.stat_n + si] = rh; ((uint32_t *)p.dstat)[3 * p.stat_n + si] = qpad ? 0u : 1u;
+    }
 
     int stage = 0;
     for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
@@ -211,9 +214,9 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
                     float gr = pacc[r];
                     if (DROP) {
                         const uint32_t bits = e < 2 ? b0 : b1;
-                        gr = ((e & 1) ? (bits >> 16) : (bits & 0xffffu)) >= thr ? gr * ik : 0.f;
+                        gr = ((e & 1) ? (bits >> 16) : (bits & 0xffffu)) >= thr ? gr : 0.f;
                     }
-                    float ds = pr * (gr - Dq);
+                    float ds = pr * (gr - Dk);                            // dS / keep_scale (dQ is scaled once, at the end)
                     if (need_mask) {
                         const bool masked = qpad || !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
                         ds = masked ? 0.f : ds;
@@ -238,28 +241,38 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
         }
     }
     if (qvalid) {
+        const float qsc = p.scale * ik;
         uint16_t *drow = (uint16_t *)p.dq + ex.dq_off + (long long)qi * p.dq_ss + n * 64;
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = j * 32 + 8 * g + 4 * hi;
-                *(uint2 *)(drow + d) = make_uint2(pack_bf16(dqacc[j][4 * g] * p.scale, dqacc[j][4 * g + 1] * p.scale),
-                                                  pack_bf16(dqacc[j][4 * g + 2] * p.scale, dqacc[j][4 * g + 3] * p.scale));
+                *(uint2 *)(drow + d) = make_uint2(pack_bf16(dqacc[j][4 * g] * qsc, dqacc[j][4 * g + 1] * qsc),
+                                                  pack_bf16(dqacc[j][4 * g + 2] * qsc, dqacc[j][4 * g + 3] * qsc));
             }
     }
 }
 
 // ========================================================== dk, dv ===================================================================
+// A wave owns 32 keys, a workgroup 128 (KNW waves); the queries stream past in steps of 32.  r04: THREE workgroups per CU (<= 168 VGPRs),
+// like the forward and the dq kernel.  The kernel is VALU-bound (~20 VALU instructions per score against 16 MFMAs per 1,024 scores), and at
+// two waves per SIMD (r03: 242 VGPRs) the vector pipe sat idle 44 % of the time -- every MFMA group waited on its own LDS fragment reads
+// with only one other wave to cover (SQ_WAIT_ANY / SQ_WAVE_CYCLES 0.38-0.45; the dq kernel, same arithmetic at three waves: 0.29).  What
+// made room: the wave's K / V fragments (B operands of S = Q K^T and dP = dO V^T, 32 registers) live in LDS next to the Q / dO stages and
+// are re-read every step, and a step is 32 queries with a double-buffered 8 KiB stage (Q + dO rows) instead of 64 queries in a
+// three-deep ring of 16 KiB stages: 32 KiB (K, V tiles of the workgroup's 128 keys) + 16 KiB (stages) + statistics = 49 KiB per workgroup.
+#define QS 32                  // queries per step
 template <bool DROP, bool CAUSAL>
-__global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(BwdParams p)
+__global__ void __launch_bounds__(KNW * 64, 3) attention_bwd_dkv_kernel(BwdParams p)
 {
-    // 3 stages x (Q tile 8 KiB + dO tile 8 KiB): two blocks of DMA in flight while one is consumed (as in attention.hip); per-query
-    // statistics of a block: pm, D, row hash, flags (64 each)
-    __shared__ __attribute__((aligned(16))) char smem[3 * 16384];
-    __shared__ __attribute__((aligned(16))) float st_pm[3][64], st_d[3][64];
-    __shared__ __attribute__((aligned(16))) uint32_t st_rh[3][64];
-    __shared__ unsigned long long st_qreal[3];
+    // [0, 16K) K tile [128 keys][64 d], [16K, 32K) V tile, then 2 stages x (Q tile [32 q][64 d] 4 KiB + dO tile 4 KiB); all tiles swizzled as in
+    // attention_common.h.  Per-query statistics of a step: pm, D, row hash (32 each) + the real-query bits
+    __shared__ __attribute__((aligned(16))) char smem[32768 + 2 * 8192];
+    __shared__ __attribute__((aligned(16))) float st_all[2][4][QS];       // [stage][pm, D, row hash (bits), real-token flag (bits)][query]
+#define st_pm(stage, q) st_all[stage][0][q]
+#define st_d(stage, q) st_all[stage][1][q]
+#define st_rh(stage, q) st_all[stage][2][q]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -274,180 +287,191 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
     const bool kvalid = key < sk;                                       // (dense: sk % 32 == 0, so a live wave's keys are all valid)
     const int kc = kvalid ? key : sk - 1;
 
+    // LDS-DMA pieces of 1 KiB = 8 rows x 128 B: lane -> (row = 8 piece + lane>>3, LDS granule = lane&7), source granule = granule ^ tile_swz(row)
+    // (tile_swz looks at row bits 1..3: period 16)
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
-    const char *q_src = p.q + (ex.q_off + (long long)n * p.q_sn) * 2 + pslot * 16;
-    const char *o_src = p.dout + (ex.qrow0 * p.heads + n) * 128 + pslot * 16;
-    const int nblk = (sq + 63) / 64;
-    const long long sbase = ex.stat0;
-    auto issue = [&](int blk, int stage) {
-        char *sb = smem + stage * 16384;
-#pragma unroll
-        for (int i = 0; i < 8 / KNW; ++i) {
-            long long qr = blk * 64 + prow + 8 * KNW * i; if (qr >= sq) qr = sq - 1;         // overhang queries re-read the last row; masked out below
-            __builtin_amdgcn_global_load_lds((gptr_t *)(q_src + qr * p.q_ss * 2), (lptr_t *)(sb + (wave + KNW * i) * 1024), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((gptr_t *)(o_src + qr * p.heads * 128), (lptr_t *)(sb + 8192 + (wave + KNW * i) * 1024), 16, 0, 0);
+    // DMA sources as a wave-uniform base (SGPRs) + a 32-bit lane offset: two 64-bit pointers per lane cost registers this kernel does not have
+    const char *q_base = p.q + (ex.q_off + (long long)n * p.q_sn) * 2;
+    const char *o_base = p.dout + (ex.qrow0 * p.heads + n) * 128;
+    const uint32_t q_row_bytes = (uint32_t)p.q_ss * 2u, o_row_bytes = (uint32_t)p.heads * 128u;     // (a sequence spans < 2^32 bytes: <= 65536 rows)
+    const int nstep = (sq + QS - 1) / QS;
+    // a step's per-query statistics (written by the dq kernel): 4 arrays x 32 queries = two LDS-DMA instructions of 64 x 4 bytes, issued by
+    // waves 0 and 1 together with their tile pieces (lane -> array 2 wave + hi, query l31)
+    const char *st_base = (const char *)(p.dstat + ex.stat0);
+    const uint32_t st_arr = (uint32_t)(2 * (wave & 1) + hi) * (uint32_t)p.stat_n * 4u;               // (4 stat_n floats < 2^32 bytes: checked on the host)
+    auto issue = [&](int step, int stage) {                                // a step's Q / dO rows: 4 + 4 pieces, one of each per wave
+        char *sb = smem + 32768 + stage * 8192;
+        const uint32_t qr = (uint32_t)min(step * QS + prow, sq - 1);            // overhang queries re-read the last row; masked out below
+        __builtin_amdgcn_global_load_lds((gptr_t *)(q_base + (__umul24(qr, q_row_bytes) + (uint32_t)(pslot * 16))), (lptr_t *)(sb + wave * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t *)(o_base + (__umul24(qr, o_row_bytes) + (uint32_t)(pslot * 16))), (lptr_t *)(sb + 4096 + wave * 1024), 16, 0, 0);
+        if (wave < 2) {
+            const uint32_t qq = (uint32_t)min(step * QS + l31, sq - 1);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(st_base + (st_arr + qq * 4u)), (lptr_t *)((char *)&st_all[stage][0][0] + wave * 256), 4, 0, 0);
         }
     };
-    issue(0, 0);                     // first Q / dO blocks in flight before this wave's K / V rows and the statistics are fetched
-    if (nblk > 1) issue(1, 1);
-
-    bf16x8 kf[4], vf[4];
-    load_row_frags(p.k + (ex.k_off + (long long)kc * p.k_ss + (long long)n * p.k_sn) * 2, hi, kf);
-    load_row_frags(p.v + (ex.v_off + (long long)kc * p.v_ss + (long long)n * p.v_sn) * 2, hi, vf);
+    issue(0, 0);                     // first Q / dO steps in flight before this wave's K / V rows and the statistics are fetched
+    {   // this wave's own 32 rows of the K and V tiles (nobody else reads them: no barrier needed, the counted wait below is enough)
+        const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2;
+        const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int trow = 8 * i + (lane >> 3);                                 // row inside this wave's 32-row slice of the tiles
+            const int slot = ((lane & 7) ^ tile_swz(trow)) * 16;
+            long long kr = k0 + trow; if (kr >= sk) kr = sk - 1;
+            __builtin_amdgcn_global_load_lds((gptr_t *)(k_src + kr * p.k_ss * 2 + slot), (lptr_t *)(smem + (wave * 4 + i) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + kr * p.v_ss * 2 + slot), (lptr_t *)(smem + 16384 + (wave * 4 + i) * 1024), 16, 0, 0);
+        }
+    }
+    if (nstep > 1) issue(1, 1);
     const bool kpad = !kvalid || p.ids_k[ex.krow0 + kc] == 0;
-    const float sc = p.scale * L2E;
+    const float sc = p.scale2;
 
-    // per-query statistics of a block, loaded by wave 0 one block ahead into registers and written to LDS a block later, so the
-    // global-load latency never sits between a barrier and the tiles' DMA
-    float nx_pm = 0.f, nx_d = 0.f;
-    uint32_t nx_rh = 0;
-    unsigned long long nx_real = 0;
-    auto load_stats = [&](int blk) {
-        const int qq = blk * 64 + lane;
-        const bool valid = qq < sq;
-        const long long si = sbase + (valid ? qq : sq - 1);
-        nx_pm = p.m[si] * L2E + __log2f(p.l[si]);
-        nx_d = p.dstat[si];
-        nx_rh = emdr2_row_hash(p.seed, (unsigned long long)si);
-        nx_real = __builtin_amdgcn_ballot_w64(valid && p.ids_q[ex.qrow0 + (valid ? qq : 0)] != 0);
-    };
-    auto store_stats = [&](int stage) {
-        st_pm[stage][lane] = nx_pm; st_d[stage][lane] = nx_d; st_rh[stage][lane] = nx_rh;
-        if (lane == 0) st_qreal[stage] = nx_real;
-    };
-    uint32_t qtr[2][2], otr[2][2], qra[4];
-    row_frag_addresses((uint32_t)(uintptr_t)smem, lane, qra);
-    tr_addresses((uint32_t)(uintptr_t)smem, lane, qtr);
-    tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, otr);
+    uint32_t qtr[2][2], qra[4], kra[4];
+    row_frag_addresses((uint32_t)(uintptr_t)smem + 32768, lane, qra);        // Q rows of stage 0; dO: + 4096; stage 1: + 8192
+    tr_addresses((uint32_t)(uintptr_t)smem + 32768, lane, qtr);               // Q^T; dO^T: + 4096
+    row_frag_addresses((uint32_t)(uintptr_t)smem + wave * 4096, lane, kra);  // this lane's key row of the K tile; V: + 16384
 
     floatx16 dkacc[2], dvacc[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { dkacc[j][r] = 0.f; dvacc[j][r] = 0.f; }
-    const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
-    const uint32_t thr = emdr2_drop_thr(p.drop_p);
+    const float ik = DROP ? p.keep_scale : 1.f;
+    const uint32_t thr = p.drop_thr;
     const uint32_t colmul = ((uint32_t)kc >> 1) * 0x9e3779b1u;           // this lane's column-pair term of emdr2_pair_bits
-    const bool codd = kc & 1;
+    const uint32_t csh = (kc & 1) ? 16u : 0u;                             // which half of the pair's 32 bits is this key's
 
-    if (wave == 0) { load_stats(0); store_stats(0); if (nblk > 1) load_stats(1); }
-    // everything fetched so far is complete here, in a form the compiler sees (cf. attention.hip): no hidden vmcnt(0) inside the loop
-    asm volatile("s_waitcnt vmcnt(0)" : "+v"(kf[0]), "+v"(kf[1]), "+v"(kf[2]), "+v"(kf[3]), "+v"(vf[0]), "+v"(vf[1]), "+v"(vf[2]), "+v"(vf[3]),
-                 "+v"(nx_pm), "+v"(nx_d), "+v"(nx_rh)::"memory");
-    int stage = 0;
-    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
-        // all but the newest block's DMA pieces (2 x 8 / KNW instructions of this wave): this block's tiles -- and, on wave 0, the statistics
-        // of the next block, which were requested BEFORE that DMA -- have arrived
-        if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / KNW)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // raw barrier: a fence would drain the look-ahead DMA
+    for (int step = 0; step < nstep; ++step) {
+        const int stage = step & 1;
+        // this step's tiles and statistics (the newest DMA of this wave; in step 0 also the K / V rows and everything else the prologue asked for)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // raw barrier (no fence needed: nothing else is in flight)
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        {
-            const int nstage = stage == 2 ? 0 : stage + 1;
-            if (blk + 1 < nblk && wave == 0) store_stats(nstage);                 // block blk + 1 (its row statistics came in an iteration ago)
-            if (blk + 2 < nblk) {
-                if (wave == 0) load_stats(blk + 2);                               // ... requested before the DMA of the same block
-                issue(blk + 2, stage == 0 ? 2 : stage - 1);
-            }
-        }
-        const int qb0 = blk * 64;
-        // keys of this wave all ahead of every query of the block: P == 0 exactly and dS == 0
-        if (!wave_live || (CAUSAL && k0 > qb0 + 63)) continue;
-        const unsigned long long qreal = st_qreal[stage];
+        // the NEXT step's rows go into the stage everybody has just left (step - 1's).  Its latency is covered by this step's arithmetic of
+        // this wave and its two SIMD mates.  (step 1 was issued in the prologue)
+        if (step >= 1 && step + 1 < nstep) issue(step + 1, stage ^ 1);
+        const int qh0 = step * QS;
+        // keys of this wave all ahead of every query of the step: P == 0 exactly and dS == 0
+        if (!wave_live || (CAUSAL && k0 > qh0 + QS - 1)) continue;
+        const uint32_t qr32 = (uint32_t)__builtin_amdgcn_ballot_w64(__float_as_uint(st_all[stage][3][l31]) != 0u);     // bit q: query q of the step is a real token
+        const uint32_t so = (uint32_t)(stage * 8192);
 
-        // the block's 64 queries in two halves of 32 (keeps the live accumulators at dK, dV + one S / dP pair)
+        const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // Five phases, so that S and dP are never live together with the statistics and hash temporaries of both (the single-pass form needed
+        // ~185 registers; an accumulator spilled to scratch once per step costs 8 KiB of traffic per wave and step, four times what the step
+        // stages): (1) S = Q K^T, (2) P and the dropped P from S -- the un-dropped P stays in the S registers with the keep bit as its SIGN --,
+        // (3) dV^T += dO^T P_d, (4) dP = dO V^T, (5) dS = |P| (keep ? dP / (1 - p) : 0 - D), dK^T += Q^T dS.
+        // Fragments by inline asm (attention_common.h: a plain load would make the compiler wait for the next step's DMA first): A = row
+        // fragments of the Q / dO tiles, B = this lane's key row of the K / V tiles.
+        // (Issuing a phase's fragment reads a phase early -- measured in four depths -- buys nothing at three waves per SIMD and costs the
+        // registers that keep the loop free of scratch traffic: reads are issued where they are used, four at a time.)
+        const uint32_t aq0[2] = {qtr[0][0] + so, qtr[0][1] + so}, aq1[2] = {qtr[1][0] + so, qtr[1][1] + so};
+        const uint32_t ao0[2] = {aq0[0] + 4096, aq0[1] + 4096}, ao1[2] = {aq1[0] + 4096, aq1[1] + 4096};
+        floatx16 sacc;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            __builtin_amdgcn_sched_barrier(0);                             // keeps the two halves' fragment reads from being hoisted together
-            const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            // row fragments of the Q and dO tiles by inline asm (attention_common.h: a plain load would wait for the next block's DMA first)
-            const uint32_t so = (uint32_t)(stage * 16384);
-            floatx16 sacc, pacc;
+        for (int t = 0; t < 4; t += 2) {
+            bf16x8 qr0, kr0, qr1, kr1;
+            LDS_READ128(qr0, qra[t] + so, 0); LDS_READ128(kr0, kra[t], 0);
+            LDS_READ128(qr1, qra[t + 1] + so, 0); LDS_READ128(kr1, kra[t + 1], 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qr0), "+v"(kr0), "+v"(qr1), "+v"(kr1)::"memory");
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr0, kr0, t == 0 ? zero : sacc, 0, 0, 0);
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr1, kr1, sacc, 0, 0, 0);
+        }
+        // this lane: one key, queries ql = 8g + 4hi + e.  Masks are rare (padding, the causal diagonal, the last query step): a wave-uniform
+        // test picks the mask-free form of the element loops otherwise
+        const bool need_mask = __builtin_amdgcn_ballot_w64(kpad) != 0ull || qr32 != 0xffffffffu || (CAUSAL && k0 + 31 > qh0) || qh0 + QS - 1 >= sq;
+        const uint32_t qbits = qr32 >> (4 * hi);                               // bit 8g + e = "query ql is a real token" for this half-wave
+        uint32_t pw[8];                                                        // dropped P, packed bf16 pairs (B operand of the dV product)
+        auto probabilities = [&](auto masks) {
+            constexpr bool MASKS = decltype(masks)::value;
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                bf16x8 qr, orr;
-                if (j == 0) { LDS_READ128(qr, qra[t] + so, 0); LDS_READ128(orr, qra[t] + so, 8192); }
-                else { LDS_READ128(qr, qra[t] + so, 4096); LDS_READ128(orr, qra[t] + so, 8192 + 4096); }
-                asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(qr), "+v"(orr)::"memory");
-                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qr, kf[t], t == 0 ? zero : sacc, 0, 0, 0);
-                pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(orr, vf[t], t == 0 ? zero : pacc, 0, 0, 0);
-            }
-            // this lane: one key, queries ql = j*32 + 8g + 4hi + e.  sacc <- dS, pacc <- dropped P.  Masks are rare (padding, the causal
-            // diagonal, the last query block): a wave-uniform test picks the mask-free form of the element loop otherwise
-            const uint32_t qr32 = (uint32_t)(qreal >> (32 * j));
-            const int qh0 = qb0 + 32 * j;
-            const bool need_mask = __builtin_amdgcn_ballot_w64(kpad) != 0ull || qr32 != 0xffffffffu || (CAUSAL && k0 + 31 > qh0) || qh0 + 31 >= sq;
-            auto elements = [&](auto masks) {
-                constexpr bool MASKS = decltype(masks)::value;
+            for (int g = 0; g < 4; ++g) {
+                const int ql0 = 8 * g + 4 * hi;
+                const float4 pm4 = *(const float4 *)&st_pm(stage, ql0);
+                uint4 rh4 = make_uint4(0, 0, 0, 0);
+                if (DROP) rh4 = *(const uint4 *)&st_rh(stage, ql0);
+                const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w};
+                const uint32_t rhv[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
+                float pdv[4];
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int ql0 = j * 32 + 8 * g + 4 * hi;
-                    const float4 pm4 = *(const float4 *)&st_pm[stage][ql0], d4 = *(const float4 *)&st_d[stage][ql0];
-                    uint4 rh4 = make_uint4(0, 0, 0, 0);
-                    if (DROP) rh4 = *(const uint4 *)&st_rh[stage][ql0];
-                    const float pmv[4] = {pm4.x, pm4.y, pm4.z, pm4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
-                    const uint32_t rhv[4] = {rh4.x, rh4.y, rh4.z, rh4.w};
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e, ql = 8 * g + 4 * hi + e, qg = qh0 + ql;
-                        bool masked = false;
-                        float pr;
-                        if (MASKS) {
-                            masked = kpad || !((qr32 >> ql) & 1u) || (CAUSAL && key > qg);
-                            pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
-                            pr = qg < sq ? pr : 0.f;                          // rows beyond sq do not exist
-                        } else {
-                            pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pmv[e]));
-                        }
-                        float gr = pacc[r], pd = pr;
-                        if (DROP) {
-                            const uint32_t bits = emdr2_pair_bits_prod(rhv[e], colmul);
-                            const float km_ = (codd ? (bits >> 16) : (bits & 0xffffu)) >= thr ? ik : 0.f;
-                            gr *= km_;
-                            pd *= km_;
-                        }
-                        const float ds = pr * (gr - dv_[e]);
-                        sacc[r] = MASKS ? (masked ? 0.f : ds) : ds;
-                        pacc[r] = pd;
+                for (int e = 0; e < 4; ++e) {
+                    const int r = 4 * g + e, qg = qh0 + 8 * g + 4 * hi + e;
+                    bool masked = false;
+                    float pr;
+                    if (MASKS) {
+                        masked = kpad || !((qbits >> (8 * g + e)) & 1u) || (CAUSAL && key > qg);
+                        pr = __builtin_amdgcn_exp2f((masked ? MASKED2 : sacc[r] * sc) - pmv[e]);
+                        pr = qg < sq ? pr : 0.f;                          // rows beyond sq do not exist
+                    } else {
+                        pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pmv[e]));
                     }
+                    float pd = pr, keep_pr = pr;
+                    if (DROP) {
+                        const uint32_t bits = emdr2_pair_bits_prod(rhv[e], colmul);
+                        const bool keep = ((bits >> csh) & 0xffffu) >= thr;
+                        keep_pr = keep ? pr : -pr;                        // P >= 0: the sign carries the keep bit to phase 5
+                        pd = fmaxf(keep_pr, 0.f);                         // dropped P in units of 1 / keep_scale (dV is scaled once, at the end)
+                    }
+                    sacc[r] = MASKS ? (masked ? 0.f : keep_pr) : keep_pr;  // masked: dS = 0 (masked_fill cuts the dependence on the score) ...
+                    pdv[e] = pd;                                          // ... while the (normally zero) probability still feeds dV, like the reference
                 }
-            };
-            if (need_mask) elements(std::true_type{});
-            else elements(std::false_type{});
-            __builtin_amdgcn_sched_barrier(0);
-            // dV^T += dO^T P_d ; dK^T += Q^T dS  (k index = the 16 queries of k-step u = 2j, 2j+1)
-#pragma unroll
-            for (int uu = 0; uu < 2; ++uu) {
-                const int r0 = uu * 8;
-                const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(pacc[r0], pacc[r0 + 1]), pack_bf16(pacc[r0 + 2], pacc[r0 + 3]),
-                                                                         pack_bf16(pacc[r0 + 4], pacc[r0 + 5]), pack_bf16(pacc[r0 + 6], pacc[r0 + 7])));
-                const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pack_bf16(sacc[r0], sacc[r0 + 1]), pack_bf16(sacc[r0 + 2], sacc[r0 + 3]),
-                                                                          pack_bf16(sacc[r0 + 4], sacc[r0 + 5]), pack_bf16(sacc[r0 + 6], sacc[r0 + 7])));
-                bf16x8 ot0, ot1, qt0, qt1;
-                const uint32_t so = (uint32_t)(stage * 16384);
-                const uint32_t ao0[2] = {otr[0][0] + so, otr[0][1] + so}, ao1[2] = {otr[1][0] + so, otr[1][1] + so};
-                const uint32_t aq0[2] = {qtr[0][0] + so, qtr[0][1] + so}, aq1[2] = {qtr[1][0] + so, qtr[1][1] + so};
-                switch (2 * j + uu) {
-                case 0: TR_FRAG2(ot0, ao0, ot1, ao1, 0); break;
-                case 1: TR_FRAG2(ot0, ao0, ot1, ao1, 1); break;
-                case 2: TR_FRAG2(ot0, ao0, ot1, ao1, 2); break;
-                default: TR_FRAG2(ot0, ao0, ot1, ao1, 3); break;
-                }
-                dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot0, pf, dvacc[0], 0, 0, 0);
-                dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot1, pf, dvacc[1], 0, 0, 0);
-                switch (2 * j + uu) {
-                case 0: TR_FRAG2(qt0, aq0, qt1, aq1, 0); break;
-                case 1: TR_FRAG2(qt0, aq0, qt1, aq1, 1); break;
-                case 2: TR_FRAG2(qt0, aq0, qt1, aq1, 2); break;
-                default: TR_FRAG2(qt0, aq0, qt1, aq1, 3); break;
-                }
-                dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf, dkacc[0], 0, 0, 0);
-                dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf, dkacc[1], 0, 0, 0);
+                pw[2 * g] = pack_bf16(pdv[0], pdv[1]); pw[2 * g + 1] = pack_bf16(pdv[2], pdv[3]);
+                __builtin_amdgcn_sched_barrier(0);     // one group of four queries at a time: interleaving the groups' hashes costs > 100 registers
             }
+        };
+        if (need_mask) probabilities(std::true_type{});
+        else probabilities(std::false_type{});
+        // dV^T += dO^T P_d  (k index = the 16 queries of k-step uu)
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * uu], pw[4 * uu + 1], pw[4 * uu + 2], pw[4 * uu + 3]));
+            bf16x8 ot0, ot1;
+            if (uu == 0) TR_FRAG2(ot0, ao0, ot1, ao1, 0);
+            else TR_FRAG2(ot0, ao0, ot1, ao1, 1);
+            dvacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot0, pf, dvacc[0], 0, 0, 0);
+            dvacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ot1, pf, dvacc[1], 0, 0, 0);
+        }
+        floatx16 pacc;
+#pragma unroll
+        for (int t = 0; t < 4; t += 2) {
+            bf16x8 or0, vr0, or1, vr1;
+            LDS_READ128(or0, qra[t] + so, 4096); LDS_READ128(vr0, kra[t], 16384);
+            LDS_READ128(or1, qra[t + 1] + so, 4096); LDS_READ128(vr1, kra[t + 1], 16384);
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(or0), "+v"(vr0), "+v"(or1), "+v"(vr1)::"memory");
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(or0, vr0, t == 0 ? zero : pacc, 0, 0, 0);
+            pacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(or1, vr1, pacc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 d4 = *(const float4 *)&st_d(stage, 8 * g + 4 * hi);
+            const float dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+            float dsv[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int r = 4 * g + e;
+                // dS / keep_scale = P (keep ? dP : 0) - P D / keep_scale; kept: P = max(q, 0), always: P = |q| (q = sacc: P with the keep bit as sign)
+                if (DROP) dsv[e] = fmaf(fmaxf(sacc[r], 0.f), pacc[r], -(__builtin_fabsf(sacc[r]) * dv_[e]));
+                else dsv[e] = sacc[r] * (pacc[r] - dv_[e]);
+            }
+            pw[2 * g] = pack_bf16(dsv[0], dsv[1]); pw[2 * g + 1] = pack_bf16(dsv[2], dsv[3]);
+        }
+        // dK^T += Q^T dS
+#pragma unroll
+        for (int uu = 0; uu < 2; ++uu) {
+            const bf16x8 dsf = __builtin_bit_cast(bf16x8, make_uint4(pw[4 * uu], pw[4 * uu + 1], pw[4 * uu + 2], pw[4 * uu + 3]));
+            bf16x8 qt0, qt1;
+            if (uu == 0) TR_FRAG2(qt0, aq0, qt1, aq1, 0);
+            else TR_FRAG2(qt0, aq0, qt1, aq1, 1);
+            dkacc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt0, dsf, dkacc[0], 0, 0, 0);
+            dkacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qt1, dsf, dkacc[1], 0, 0, 0);
         }
     }
+#undef st_pm
+#undef st_d
+#undef st_rh
     if (kvalid) {
+        const float ksc = p.scale * ik;                                // the step loop accumulated dS and the dropped P in units of 1 / keep_scale
         uint16_t *krow = (uint16_t *)p.dk + ex.dkv_off + (long long)key * p.dkv_ss + n * 64;
         uint16_t *vrow = (uint16_t *)p.dv + ex.dkv_off + (long long)key * p.dkv_ss + n * 64;
 #pragma unroll
@@ -455,9 +479,9 @@ __global__ void __launch_bounds__(KNW * 64, DKV_OCC) attention_bwd_dkv_kernel(Bw
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int d = j * 32 + 8 * g + 4 * hi;
-                *(uint2 *)(krow + d) = make_uint2(pack_bf16(dkacc[j][4 * g] * p.scale, dkacc[j][4 * g + 1] * p.scale),
-                                                  pack_bf16(dkacc[j][4 * g + 2] * p.scale, dkacc[j][4 * g + 3] * p.scale));
-                *(uint2 *)(vrow + d) = make_uint2(pack_bf16(dvacc[j][4 * g], dvacc[j][4 * g + 1]), pack_bf16(dvacc[j][4 * g + 2], dvacc[j][4 * g + 3]));
+                *(uint2 *)(krow + d) = make_uint2(pack_bf16(dkacc[j][4 * g] * ksc, dkacc[j][4 * g + 1] * ksc),
+                                                  pack_bf16(dkacc[j][4 * g + 2] * ksc, dkacc[j][4 * g + 3] * ksc));
+                *(uint2 *)(vrow + d) = make_uint2(pack_bf16(dvacc[j][4 * g] * ik, dvacc[j][4 * g + 1] * ik), pack_bf16(dvacc[j][4 * g + 2] * ik, dvacc[j][4 * g + 3] * ik));
             }
     }
 }
@@ -488,6 +512,9 @@ static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.dq_sb = dq_sb; p.dq_ss = dq_ss; p.dkv_sb = dkv_sb; p.dkv_ss = dkv_ss;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
+    p.stat_n = cu_q ? (long long)heads * total_q : (long long)batch * heads * sq;
+    if (p.stat_n * 16 >= (1ll << 32) || q_ss >= (1 << 22) || heads >= (1 << 16)) return -4;     // 32-bit lane offsets of the dk/dv kernel's staging
+    p.keep_scale = emdr2_keep_scale(drop_p); p.inv_keep_scale = 1.f / p.keep_scale; p.scale2 = scale * L2E; p.drop_thr = emdr2_drop_thr(drop_p);
     OpsTimer timer(OPS_ATTN_BWD, 10.0 * heads * pairs * 64, (hipStream_t)stream);
     const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads, heads));
     const size_t dq_lds = 3 * 16384 + (size_t)((sk + 63) / 64) * 8;

@@ -841,7 +841,9 @@ class AttentionCoreFn(torch.autograd.Function):
         dctx = dctx.contiguous()
         H = heads * hn
         lib = _lib()
-        D = torch.empty_like(m)
+        # scratch of the fused kernels: four per-query statistics (exp2 offset, D = rowsum(dout * o), dropout row hash, real-token flag) the dq
+        # kernel leaves for the dk / dv kernel (include/emdr2_ops.h); the unfused path below uses the first [b, heads, sq] as D
+        D = torch.empty((4,) + tuple(m.shape), dtype=torch.float32, device=dev)
         if pq or pk:
             pairs = ids_q.pairs if (pq and ids_k is ids_q) else (sq * ids_k.total if not pq else 0)
             _native.check(lib.emdr2_attention_varlen_bwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,

@@ -87,8 +87,10 @@ int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
 
 /* Fused attention backward for the same shapes (csrc/attention_bwd.hip): dq, dk, dv [b, s, heads, 64] with caller-given batch / sequence element
  * strides (heads 64 apart: they may be slices of one packed QKV gradient) from q, k, v (strided views),
- * the forward output o and its gradient dout (contiguous), and the forward's m, l.  dstat (fp32 [b, heads, sq]) is scratch for
- * D = rowsum(dout * o).  Same masks, scale and dropout stream as the forward. */
+ * the forward output o and its gradient dout (contiguous), and the forward's m, l.  dstat (fp32 [4, b, heads, sq], caller-owned scratch;
+ * ABI 2: four times the ABI-1 size) receives what the dq kernel leaves for the dk / dv kernel per query: the exp2 offset
+ * m log2(e) + log2(l), D = rowsum(dout * o), the dropout row hash and the real-token flag (the last two as bit patterns).
+ * Same masks, scale and dropout stream as the forward. */
 int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
                         const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb, int64_t dq_ss,
                         void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss,
@@ -122,7 +124,7 @@ int emdr2_embedding_packed_bwd(const int64_t *ids_packed, const int64_t *types_p
 /* The fused attention kernels over packed operands (same kernels as emdr2_attention_fwd / _bwd): cu_q and / or cu_k (int32 [batch+1], either
  * may be NULL = that side is dense [batch, s] with its batch stride) give sequence b's rows [cu[b], cu[b+1]) of q / o / dq (k, v / dk, dv);
  * ids_q / ids_k are indexed the same way (packed ids for a packed side).  max_sq / max_sk: the longest sequence (grid size; dense side: s);
- * a packed key side takes ANY lengths >= 1 (keys past the end are masked).  With cu_q the row statistics m, l, dstat are [heads, total_q].
+ * a packed key side takes ANY lengths >= 1 (keys past the end are masked).  With cu_q the row statistics m, l are [heads, total_q] and dstat is [4, heads, total_q].
  * pairs = sum_b sq_b * sk_b (flop accounting of the timing hooks only).  Replaces transformer.py:283-381 for the packed stacks and the
  * FiD cross-attention of emdr2_model.py:166-183 over the packed encoder output (cu_k = every K-th entry of the encoder's cu). */
 int emdr2_attention_varlen_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
