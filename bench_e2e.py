@@ -186,7 +186,7 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(plan=plan, oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(make_batch=make_batch, retriever=retr, sched=sched, plan=plan, oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 

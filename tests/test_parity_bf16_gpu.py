@@ -75,8 +75,10 @@ def _check(report, name, a, b, tol, b32=None):
     report.append(dict(name=name, max=e_max / s_max, rms=e_rms / s_rms, noise_max=n_max / s_max, noise_rms=n_rms / s_rms, tol=tol, ok=ok))
 
 
-def _assert_report(report):
-    """All tensors are measured first, then every violator is listed (one run shows the whole picture)."""
+def _assert_report(report, max_admitted=0):
+    """All tensors are measured first, then every violator is listed (one run shows the whole picture).  `max_admitted` bounds how many tensors
+    may pass by the noise clause only: the count measured when the bound was set (r04) plus a small margin -- a change that pushes more
+    tensors out of the plain tolerance fails here even if each of them is still within 3 x its own bf16 noise."""
     fmt = lambda r: "%s: max %.3g rms %.3g (tol %.3g / %.3g; own bf16 noise %.3g / %.3g)" % (r["name"], r["max"], r["rms"], r["tol"][0], r["tol"][1],
                                                                                          r["noise_max"], r["noise_rms"])
     within = [r for r in report if r["max"] <= r["tol"][0] and r["rms"] <= r["tol"][1]]
@@ -87,6 +89,8 @@ def _assert_report(report):
     for b in bad:
         print("VIOLATION", b)
     assert not bad, "%d tensors outside their bounds (listed above)" % len(bad)
+    admitted = sum(r["ok"] for r in report) - len(within)
+    assert admitted <= max_admitted, "%d tensors pass only by their own-noise clause (bound %d)" % (admitted, max_admitted)
 
 
 def _check_grads(report, module, P, P32, prefix, tol):
@@ -236,7 +240,7 @@ def _check_layers(report, tap, heads):
             _check(report, name + " d " + k, p.grad, P[name + "." + k].grad, LAYER_GRAD, P32[name + "." + k].grad)
 
 
-def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, perturb, layerwise):
+def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, perturb, layerwise, max_admitted=0):
     from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
@@ -261,7 +265,7 @@ def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, pert
     report = []
     if layerwise:
         _check_layers(report, tap, oracle_cfg["heads"])
-        _assert_report(report)
+        _assert_report(report, max_admitted)
         return len(tap.records)
 
     def oracle(P):
@@ -279,19 +283,21 @@ def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, pert
     for name, got, ref, ref32 in (("lm_loss", float(stats["lm_loss"]), lm_loss_r, lm_loss32), ("retriever_loss", float(stats["retriever_loss"]), r_loss_r, r_loss32)):
         assert abs(got - ref) <= max(2e-3 * abs(ref), NOISE_X_ACT * abs(ref - ref32)), (name, got, ref, ref32)
     _check_grads(report, m, P, P32, "", E2E_GRAD)
-    _assert_report(report)
+    _assert_report(report, max_admitted)
     return 0
 
 
 def test_emdr2_step_vs_bf16_faithful_oracle():
     """Rows a9-a14 at test dimensions: forward triple, both losses and every parameter gradient."""
-    _emdr2_case({}, CFG, B=4, Kk=8, S_ret=32, S=64, L=32, V_t5=640, V_bert=512, seed=7, perturb=0.05, layerwise=False)
+    _emdr2_case({}, CFG, B=4, Kk=8, S_ret=32, S=64, L=32, V_t5=640, V_bert=512, seed=7, perturb=0.05, layerwise=False,
+                max_admitted=16)                                  # r04: 12 of 132 tensors needed the noise clause
 
 
 def test_every_layer_teacher_forced_vs_bf16_faithful_oracle():
     """All four stacks of the EMDR2 step at test dimensions (query tower, context tower, reader encoder, FiD decoder): each layer's output,
     input gradient and parameter gradients from the HIP path's own input and upstream gradient."""
-    n = _emdr2_case({}, CFG, B=4, Kk=8, S_ret=32, S=64, L=32, V_t5=640, V_bert=512, seed=7, perturb=0.05, layerwise=True)
+    n = _emdr2_case({}, CFG, B=4, Kk=8, S_ret=32, S=64, L=32, V_t5=640, V_bert=512, seed=7, perturb=0.05, layerwise=True,
+                    max_admitted=22)                              # r04: 16 of 128
     assert n == 8                                               # 2 layers x (query, context, reader encoder, reader decoder)
 
 
@@ -304,12 +310,12 @@ def test_base_size_emdr2_step_vs_bf16_faithful_oracle():
     (megatron/model/transformer.py:474-563 twelve times per stack, emdr2_model.py:87-214, train_e2eqa.py:72-181)."""
     torch.set_num_threads(min(64, torch.get_num_threads() or 1))
     _emdr2_case(dict(max_pos=512, std=0.02, **BASE), BASE, B=2, Kk=4, S_ret=256, S=512, L=32, V_t5=30720, V_bert=30592, seed=11, perturb=0.01,
-                layerwise=False)
+                layerwise=False, max_admitted=340)               # r04: 313 of 692 (gradients through twelve bf16 layers per stack)
 
 
 def test_every_layer_of_the_base_size_model_teacher_forced():
     """The same model and batch: all 48 layers, each from the HIP path's own input and upstream gradient."""
     torch.set_num_threads(min(64, torch.get_num_threads() or 1))
     n = _emdr2_case(dict(max_pos=512, std=0.02, **BASE), BASE, B=2, Kk=4, S_ret=256, S=512, L=32, V_t5=30720, V_bert=30592, seed=11, perturb=0.01,
-                    layerwise=True)
+                    layerwise=True, max_admitted=135)             # r04: 119 of 768
     assert n == 48
