@@ -45,8 +45,8 @@ struct Workspace {
     char *q_frag;
     char *q_tiled;
     float *qnorm, *tau;
-    unsigned *count;
-    uint2 *cand;
+    unsigned *count;       // [512] main-list counts, then [8][512] sub-list counts, then the pair-progress counters
+    uint2 *cand, *cand8;
 };
 
 size_t carve(char *base, int dim, Workspace *w)
@@ -57,9 +57,10 @@ size_t carve(char *base, int dim, Workspace *w)
     char *a = take((size_t)(dim / 32) * 512 * 64);
     char *b = take(512 * sizeof(float));
     char *c = take(512 * sizeof(float));
-    char *d = take((512 + 8 * (size_t)SCAN8_PROG_UINTS) * sizeof(unsigned));       // per-query candidate counts + pair progress counters of up to 8 scan8 launches
+    char *d = take((512 + 8 * 512 + 8 * (size_t)SCAN8_PROG_UINTS) * sizeof(unsigned));       // candidate counts (main, per-XCD) + pair progress counters of up to 8 scan8 launches
     char *e = take((size_t)512 * CAPQ * sizeof(uint2));
-    if (w) { w->q_frag = f; w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; }
+    char *g = take((size_t)512 * 8 * SUBCAP * sizeof(uint2));
+    if (w) { w->q_frag = f; w->q_tiled = a; w->qnorm = (float *)b; w->tau = (float *)c; w->count = (unsigned *)d; w->cand = (uint2 *)e; w->cand8 = (uint2 *)g; }
     return off;
 }
 
@@ -140,7 +141,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
     hipStream_t stream = (hipStream_t)stream_;
     const int kp = k <= 56 ? 64 : 128;
     const int seg0 = env_int("EMDR2_MIPS_SEG0", 8192) / 512 * 512;
-    const int growth = env_int("EMDR2_MIPS_GROWTH", 16);
+    const int growth = env_int("EMDR2_MIPS_GROWTH", 8);    // r04: 8 (was 16): with cheaper selects a tighter threshold for the next segment pays (tools/mips_timeline.py)
     if (seg0 < 512 || seg0 > (int)CAPQ - 512 || growth < 2) return EMDR2_E_BADARG;
     const int force_variant = env_int("EMDR2_MIPS_VARIANT", -1);
     const int cus = env_int("EMDR2_MIPS_GRID", cu_count());
@@ -159,7 +160,11 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         if (variant == 0 && scan_kernel == 5 && (rc = mips_launch_pack_queries_frag(qp, nqp, dim, w.q_frag, stream))) return rc;
 #endif
         const int64_t dense_rows = n_rows < seg0 ? n_rows : seg0;
-        if ((rc = mips_launch_init(w.tau, w.count, out_flags + q0, BN, nqp, (unsigned)dense_rows, stream))) return rc;
+        unsigned *const count8 = w.count + 512, *const prog0 = count8 + 8 * 512;
+        // thresholds, counts, flags -- and the sub-list counts and pair-progress counters of the persistent scan launches -- in one launch
+        if ((rc = mips_launch_init(w.tau, w.count, out_flags + q0, BN, nqp, (unsigned)dense_rows, count8,
+                                   8 * 512 + (variant == 0 ? 8 * (size_t)SCAN8_PROG_UINTS : 0), stream)))
+            return rc;
 
         ScanParams sp;
         sp.e_tiled = (const char *)tiled;
@@ -173,18 +178,18 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         sp.n_rows = (int)n_rows;
         sp.n_q = nqp;
         sp.capq = CAPQ;
+        sp.cand8 = w.cand8;
+        sp.count8 = count8;
         sp.dense_row0 = 0;
         sp.tune = env_int("EMDR2_MIPS_TUNE", 17);
         sp.trace = (unsigned long long *)w.cand + (size_t)511 * CAPQ; // scratch tail of the candidate area (ABL 9 only)
 
-        unsigned *const prog0 = w.count + 512;
         int scan8_launches = 0;
 #ifdef EMDR2_EXPERIMENTS
         const bool couple = env_int("EMDR2_MIPS_COUPLE", 1) != 0;
 #else
         const bool couple = true;
 #endif
-        if (variant == 0 && hipMemsetAsync(prog0, 0, 8 * (size_t)SCAN8_PROG_UINTS * sizeof(unsigned), stream) != hipSuccess) return EMDR2_E_LAUNCH;
         int64_t done = 0, seg_end = dense_rows;
         int64_t next_boundary = (int64_t)seg0 * growth;
         int mode = 1;
@@ -229,7 +234,8 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
                 g_timing.rows[g_timing.n] = seg_end - done;
                 ++g_timing.n;
             }
-            if ((rc = mips_launch_select(w.cand, w.count, w.tau, out_flags + q0, CAPQ, kp, nqp, stream))) return rc;
+            // (the select after the LAST segment runs inside the finalize launch)
+            if (seg_end < n_rows && (rc = mips_launch_select(w.cand, w.count, w.cand8, count8, w.tau, out_flags + q0, CAPQ, kp, nqp, stream))) return rc;
             done = seg_end;
             seg_end = next_boundary < n_rows ? next_boundary : n_rows;
             if (n_rows - seg_end < seg_end / 2) seg_end = n_rows; // do not leave a short tail for a last launch (a launch + a select cost ~70 us)
@@ -242,6 +248,8 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         fp.queries = qp;
         fp.cand = w.cand;
         fp.count = w.count;
+        fp.cand8 = w.cand8;
+        fp.count8 = count8;
         fp.tau = w.tau;
         fp.qnorm = w.qnorm;
         fp.emax_sq = emax_sq;
@@ -258,7 +266,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         fp.k = k;
         fp.kp = kp;
         fp.capq = CAPQ;
-        if ((rc = mips_launch_finalize(fp, stream))) return rc;
+        if ((rc = mips_launch_finalize(fp, true, stream))) return rc;
     }
     return EMDR2_OK;
 }
@@ -379,6 +387,8 @@ int emdr2_mips_debug_scores(const void *tiled, int64_t n_rows, int dim, const vo
     sp.n_rows = (int)n_rows;
     sp.n_q = n_q;
     sp.capq = CAPQ;
+    sp.cand8 = nullptr;
+    sp.count8 = nullptr;
     sp.dense_row0 = 0;
     sp.tune = 1;
     sp.trace = nullptr;

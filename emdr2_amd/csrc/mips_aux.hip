@@ -129,7 +129,7 @@ int mips_launch_pack_queries(const void *queries, int n_q, int dim, int bn, void
     return CHECK_LAUNCH();
 }
 
-__global__ void init_kernel(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count)
+__global__ void init_kernel(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count, uint4 *zero16, unsigned n_zero16)
 {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < bn) {
@@ -137,12 +137,17 @@ __global__ void init_kernel(float *tau, unsigned *count, unsigned *flags, int bn
         count[i] = (i < n_q) ? dense_count : 0u;
     }
     if (i < n_q) flags[i] = 0u;
+    // the pair-progress counters of the persistent scan launches (mips_scan8.hip), zeroed here instead of by a memset of their own
+    for (unsigned j = (unsigned)i; j < n_zero16; j += gridDim.x * blockDim.x) zero16[j] = make_uint4(0u, 0u, 0u, 0u);
 }
 
-int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count,
+int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count, unsigned *zero, size_t n_zero,
                      hipStream_t stream)
 {
-    hipLaunchKernelGGL(init_kernel, dim3((bn + 255) / 256), dim3(256), 0, stream, tau, count, flags, bn, n_q, dense_count);
+    if (n_zero & 3) return -1;
+    const int blocks = zero && n_zero ? 128 : (bn + 255) / 256;
+    hipLaunchKernelGGL(init_kernel, dim3(blocks < (bn + 255) / 256 ? (bn + 255) / 256 : blocks), dim3(256), 0, stream, tau, count, flags, bn, n_q, dense_count,
+                       (uint4 *)zero, (unsigned)(zero ? n_zero / 4 : 0));
     return CHECK_LAUNCH();
 }
 
@@ -175,57 +180,130 @@ __device__ __forceinline__ void pick_digit(const unsigned *hist, unsigned need, 
     }
 }
 
-__global__ void __launch_bounds__(256) select_kernel(uint2 *cand_all, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp)
+// One block of 256 threads reduces query q's candidate list to its kp largest keys (radix select, 8 digits of 8 bits from the top) and sets
+// tau[q] to the kp-th score.  r04: lists of up to SEL_LDS keys (the dense first segment has 8,192) are staged in LDS once instead of being
+// re-read from L2 by each of the eight passes, and a thread adds RUNS of equal digits to the histogram with one atomic -- scores of one query
+// share their sign / exponent byte, so the first passes used to serialise thousands of LDS atomics on one or two bins (96 us for the first
+// select of a search, 18 us for the later ones: a third of what a search on an N / 8 row shard spends outside its scan).
+#define SEL_LDS 8192
+struct SelectShared {
+    uint64_t key[SEL_LDS];
+    unsigned hist[256];
+    unsigned digit, need, out;
+    uint2 keep[128];
+};
+// entry i of query q's whole candidate set: the main list [0, n_main) followed by the eight per-XCD sub-lists (lengths sub[x])
+struct CandView {
+    const uint2 *main_list, *sub_lists;   // [capq], [8][SUBCAP]
+    unsigned n_main, sub_end[8];          // sub_end[x] = n_main + sub[0] + .. + sub[x]
+    __device__ __forceinline__ uint2 at(unsigned i) const
+    {
+        if (i < n_main) return main_list[i];
+        unsigned lo = n_main;
+#pragma unroll
+        for (int x = 0; x < 8; ++x) {
+            if (i < sub_end[x]) return sub_lists[x * SUBCAP + (i - lo)];
+            lo = sub_end[x];
+        }
+        return main_list[0];
+    }
+};
+
+__device__ __forceinline__ void select_block(SelectShared &sh, uint2 *cand_all, unsigned *count, uint2 *cand8, unsigned *count8, float *tau, unsigned *flags,
+                                             unsigned capq, int kp, int q)
 {
-    __shared__ unsigned hist[256];
-    __shared__ unsigned sh_digit, sh_need, sh_out;
-    __shared__ uint2 keep[128];
-    const int q = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     uint2 *cand = cand_all + (size_t)q * capq;
+    CandView cv;
+    cv.main_list = cand;
+    cv.sub_lists = cand8 ? cand8 + (size_t)q * 8 * SUBCAP : nullptr;
     unsigned n = count[q];
     if (n > capq) { if (tid == 0) { atomicOr(&flags[q], 2u); count[q] = capq; } n = capq; }
-    if (n <= (unsigned)kp) return;
-
+    cv.n_main = n;
+    bool any_sub = false;
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+        unsigned m = cand8 ? count8[x * 512 + q] : 0u;
+        if (m > SUBCAP) { if (tid == 0) atomicOr(&flags[q], 2u); m = SUBCAP; }          // a sub-list overflowed: candidates were lost -> exact fallback
+        any_sub |= m != 0;
+        n += m;
+        cv.sub_end[x] = n;
+    }
+    __syncthreads();                                                  // (everybody has read the sub-list counts before they are reset below)
+    if (any_sub && tid < 8) count8[tid * 512 + q] = 0;                // the next segment appends to empty sub-lists
+    if (n <= (unsigned)kp) {
+        if (any_sub) {                                                // fewer than kp candidates in all: move the sub-list entries behind the main ones
+            for (unsigned i = cv.n_main + tid; i < n; i += 256) cand[i] = cv.at(i);
+            if (tid == 0) count[q] = n;
+        }
+        return;
+    }
+    const bool staged = n <= SEL_LDS;
+    if (staged) {
+        // eight loads in flight per thread (one at a time, the 32 rounds of an 8,192-entry list each paid a full L2 latency)
+        for (unsigned i0 = tid; i0 < n; i0 += 8 * 256) {
+            uint2 e[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const unsigned i = i0 + j * 256; e[j] = cv.at(i < n ? i : n - 1); }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const unsigned i = i0 + j * 256; if (i < n) sh.key[i] = cand_key(e[j]); }
+        }
+    }
     uint64_t prefix = 0, mask = 0;
     unsigned need = (unsigned)kp;
     for (int pass = 0; pass < 8; ++pass) {
         const int shift = 56 - 8 * pass;
-        hist[tid] = 0;
+        sh.hist[tid] = 0;
         __syncthreads();
+        unsigned run_digit = 0xffffffffu, run = 0;
         for (unsigned i = tid; i < n; i += 256) {
-            const uint64_t k = cand_key(cand[i]);
-            if ((k & mask) == prefix) atomicAdd(&hist[(unsigned)(k >> shift) & 255u], 1u);
+            const uint64_t k = staged ? sh.key[i] : cand_key(cv.at(i));
+            if ((k & mask) == prefix) {
+                const unsigned d = (unsigned)(k >> shift) & 255u;
+                if (d != run_digit) {
+                    if (run) atomicAdd(&sh.hist[run_digit], run);
+                    run_digit = d; run = 0;
+                }
+                ++run;
+            }
         }
+        if (run) atomicAdd(&sh.hist[run_digit], run);
         __syncthreads();
-        if (tid < 64) pick_digit(hist, need, &sh_digit, &sh_need);
+        if (tid < 64) pick_digit(sh.hist, need, &sh.digit, &sh.need);
         __syncthreads();
-        prefix |= (uint64_t)sh_digit << shift;
+        prefix |= (uint64_t)sh.digit << shift;
         mask |= (uint64_t)0xff << shift;
-        need = sh_need;
+        need = sh.need;
         __syncthreads();
     }
     // prefix is now the kp-th largest key; keys are unique, so exactly kp keys are >= prefix
-    if (tid == 0) sh_out = 0;
+    if (tid == 0) sh.out = 0;
     __syncthreads();
     for (unsigned i = tid; i < n; i += 256) {
-        const uint2 e = cand[i];
-        if (cand_key(e) >= prefix) {
-            const unsigned s = atomicAdd(&sh_out, 1u);
-            if (s < 128) keep[s] = e;
+        const uint64_t k = staged ? sh.key[i] : cand_key(cv.at(i));
+        if (k >= prefix) {                                            // (a key is its entry: score bits from the ordered form, row from the low word)
+            const unsigned s = atomicAdd(&sh.out, 1u);
+            if (s < 128) sh.keep[s] = make_uint2(__float_as_uint(f32_unorder((uint32_t)(k >> 32))), 0xffffffffu - (uint32_t)k);
         }
     }
     __syncthreads();
-    if (tid < kp) cand[tid] = keep[tid];
+    if (tid < kp) cand[tid] = sh.keep[tid];
     if (tid == 0) {
         count[q] = (unsigned)kp;
         tau[q] = f32_unorder((uint32_t)(prefix >> 32));
     }
 }
 
-int mips_launch_select(uint2 *cand, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
+__global__ void __launch_bounds__(256) select_kernel(uint2 *cand_all, unsigned *count, uint2 *cand8, unsigned *count8, float *tau, unsigned *flags, unsigned capq, int kp)
+{
+    __shared__ SelectShared sh;
+    select_block(sh, cand_all, count, cand8, count8, tau, flags, capq, kp, blockIdx.x);
+}
+
+int mips_launch_select(uint2 *cand, unsigned *count, uint2 *cand8, unsigned *count8, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
                        hipStream_t stream)
 {
-    hipLaunchKernelGGL(select_kernel, dim3(n_q), dim3(256), 0, stream, cand, count, tau, flags, capq, kp);
+    hipLaunchKernelGGL(select_kernel, dim3(n_q), dim3(256), 0, stream, cand, count, cand8, count8, tau, flags, capq, kp);
     return CHECK_LAUNCH();
 }
 
@@ -251,11 +329,20 @@ __device__ __forceinline__ void exact_dot_wave(const char *e_tiled, int64_t row,
     hi_out = wave_sum_i64(hi);
 }
 
+template <bool SELECT_FIRST>
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
 {
     __shared__ uint64_t fkey[128];
     __shared__ uint32_t sh_kth;
     const int q = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if constexpr (SELECT_FIRST) {
+        // the select that follows the LAST scan segment, run by the block that consumes its result (one launch less per search; the list, its
+        // count and tau go through global memory as between two kernels: the fence orders them for this block's own reads below)
+        __shared__ SelectShared sel;
+        select_block(sel, (uint2 *)p.cand, (unsigned *)p.count, p.cand8, p.count8, (float *)p.tau, p.flags, p.capq, p.kp, q);
+        __threadfence_block();
+        __syncthreads();
+    }
     const uint2 *cand = p.cand + (size_t)q * p.capq;
     unsigned cnt = p.count[q];
     if (cnt > (unsigned)p.kp) cnt = p.kp;
@@ -308,9 +395,10 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
     }
 }
 
-int mips_launch_finalize(const FinalizeParams &p, hipStream_t stream)
+int mips_launch_finalize(const FinalizeParams &p, bool select_first, hipStream_t stream)
 {
-    hipLaunchKernelGGL(finalize_kernel, dim3(p.n_q), dim3(256), 0, stream, p);
+    if (select_first) hipLaunchKernelGGL(finalize_kernel<true>, dim3(p.n_q), dim3(256), 0, stream, p);
+    else hipLaunchKernelGGL(finalize_kernel<false>, dim3(p.n_q), dim3(256), 0, stream, p);
     return CHECK_LAUNCH();
 }
 

@@ -4,6 +4,7 @@
 #include <stdint.h>
 
 #define CAPQ 16384u /* candidate slots per query (8 B each) */
+#define SUBCAP 1024u /* ... plus 8 sub-lists of this many per query, one per XCD, filled by the persistent scan (mips_scan8.hip) */
 
 struct ScanParams {
     const char *e_tiled;  // stripe-tiled index image
@@ -18,6 +19,8 @@ struct ScanParams {
     int n_rows;           // valid rows of the shard
     int n_q;
     unsigned capq;
+    uint2 *cand8;         // [BN][8][SUBCAP]: per-XCD candidate sub-lists of the persistent scan (nullptr: not used)
+    unsigned *count8;     // [8][512]
     int dense_row0;       // MODE 1: first row of the dense segment
     int tune;             // bits (EMDR2_MIPS_TUNE, default 17): 1 = prio on MFMA phase, 2 = prio on load phase, 4 = DMA before reads, 16 = non-temporal index-row loads (+5 % in the HBM-bound regime)
     unsigned long long *trace; // ABL 9: s_memtime stamps [16 chunks][8 waves][10 points]
@@ -45,10 +48,10 @@ int mips_launch_unpack_rows(const void *tiled, int dim, const int64_t *row_ids, 
 // queries row-major fp16 [n_q, dim] -> chunk-tiled image for BN rows (zero padded) + ||q||_2 upper bounds
 int mips_launch_pack_queries(const void *queries, int n_q, int dim, int bn, void *q_tiled, float *qnorm,
                              hipStream_t stream);
-int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count,
+int mips_launch_init(float *tau, unsigned *count, unsigned *flags, int bn, int n_q, unsigned dense_count, unsigned *zero, size_t n_zero,
                      hipStream_t stream);
 // keep the kp best candidates of every query (by (score desc,row asc)), publish tau = kp-th score
-int mips_launch_select(uint2 *cand, unsigned *count, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
+int mips_launch_select(uint2 *cand, unsigned *count, uint2 *cand8, unsigned *count8, float *tau, unsigned *flags, unsigned capq, int kp, int n_q,
                        hipStream_t stream);
 // exact re-scoring of the surviving candidates, canonical order, validity proof, outputs
 struct FinalizeParams {
@@ -56,6 +59,8 @@ struct FinalizeParams {
     const uint16_t *queries; // row-major [n_q, dim]
     const uint2 *cand;
     const unsigned *count;
+    uint2 *cand8;            // per-XCD sub-lists of the last scan segment (select_first), or nullptr
+    unsigned *count8;
     const float *tau;
     const float *qnorm;
     const float *emax_sq;
@@ -69,7 +74,7 @@ struct FinalizeParams {
     unsigned capq;
     int f32;                 // 1: FaissMIPSIndex-style scores RNE_fp32(exact dot), order (fp32 score desc, row asc)
 };
-int mips_launch_finalize(const FinalizeParams &p, hipStream_t stream);
+int mips_launch_finalize(const FinalizeParams &p, bool select_first, hipStream_t stream);      // select_first: run the select of the last scan segment in the same launch
 int mips_launch_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
                           float *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
 int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,

@@ -383,382 +383,9 @@ __device__ __forceinline__ void filter_tile_direct(const ScanParams &p, const fl
     if (__builtin_amdgcn_ballot_w64(stored)) wait_vmcnt0(); // keep the counted LDS-DMA waits exact
 }
 
-#ifdef EMDR2_EXPERIMENTS   // schedule variants kept for tools/ (ping-pong, q8): measured within +-4 % of the lockstep kernel, DESIGN 5.3
-template <int N> __device__ __forceinline__ void wait_vmcnt_n();
-template <> __device__ __forceinline__ void wait_vmcnt_n<4>() { asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt_n<5>() { asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt_n<8>() { asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); }
-template <> __device__ __forceinline__ void wait_vmcnt_n<10>() { asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); }
-
-// NS = ring depth (3 with the LDS survivor queue, 4 = all 160 KiB of LDS, survivors go direct)
-template <int WM, int WN, int NS, int ABL = 0>
-__global__ void __launch_bounds__(512) mips_scan_pp_kernel(ScanParams p)
-{
-    constexpr int BM = WM * 64, BN = WN * 128;
-    constexpr int E_STAGE = BM * 64, Q_STAGE = BN * 64, STAGE = E_STAGE + Q_STAGE;
-    constexpr int E_PW = BM / 128, Q_PW = BN / 128, PPW = E_PW + Q_PW;
-    constexpr int STRIPES_PER_TILE = BM / STRIPE_ROWS;
-    constexpr bool QUEUE = (NS == 3);
-    constexpr int INFLIGHT = (NS - 2) * PPW; // LDS-DMA pieces of later chunks allowed outstanding at a wait
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const qbuf = smem + NS * STAGE;
-    unsigned *const qcnt = (unsigned *)(qbuf + QCAP * 16);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int group = wave >> 2;
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int swz = (l31 >> 2) & 3;
-
-    const int first_tile = p.tile_begin + (int)blockIdx.x;
-    if (first_tile >= p.tile_end) return;
-    if (QUEUE && tid == 0) *qcnt = 0;
-
-    int a_off[2], b_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-        const int sp = ((ks * 2 + hi) ^ swz) << 4;
-        a_off[ks] = (wm * 64 + l31) * 64 + sp;
-        b_off[ks] = E_STAGE + (wn * 128 + l31) * 64 + sp;
-    }
-    float tau[4];
-#pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
-        const int q = wn * 128 + ni * 32 + l31;
-        tau[ni] = (q < p.n_q && (ABL == 0 || ABL == 8 || ABL == 9)) ? p.tau[q] : __builtin_inff();
-    }
-    const unsigned qbase = wn * 128 + l31;
-
-    const int nch = p.nch;
-    const int tstep = (int)gridDim.x;
-    int pf_tile = first_tile, pf_c = 0, pf_stage = 0;
-    auto issue = [&]() {
-        const int t = pf_tile < p.tile_end ? pf_tile : first_tile;
-        char *sb = smem + pf_stage * STAGE;
-#pragma unroll
-        for (int j = 0; j < E_PW; ++j) {
-            const int pe = wave + 8 * j;
-            const size_t stripe = (size_t)t * STRIPES_PER_TILE + (pe >> 3);
-            if (ABL != 3 && ABL != 14 && ABL != 15) glds16(p.e_tiled + (stripe * nch + pf_c) * STRIPE_CHUNK_BYTES + (pe & 7) * 1024 + lane * 16, sb + pe * 1024);
-        }
-#pragma unroll
-        for (int j = 0; j < Q_PW; ++j) {
-            const int pq = wave + 8 * j;
-            if (ABL != 3 && ABL != 14 && ABL != 15) glds16(p.q_tiled + (size_t)pf_c * Q_STAGE + pq * 1024 + lane * 16, sb + E_STAGE + pq * 1024);
-        }
-        if (++pf_c == nch) { pf_c = 0; pf_tile += tstep; }
-        pf_stage = (pf_stage == NS - 1) ? 0 : pf_stage + 1;
-    };
-    auto maybe_flush = [&]() { // all 8 waves run this right after the same barrier event
-        if (!QUEUE) return;
-        const unsigned n = *(volatile __attribute__((address_space(3))) unsigned *)qcnt;
-        if (n >= FLUSH_AT) {
-            flush_queue(p, qbuf, qcnt, n, tid);
-            __syncthreads();
-            if (tid == 0) *qcnt = 0;
-            __syncthreads();
-        }
-    };
-
-    floatx16 acc[2][4];
-    Frags f;
-    int cs = 0;
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 4; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
-
-    if (ABL == 8 && blockIdx.x == 0 && tid == 0) { p.trace[1280] = __builtin_amdgcn_s_memtime(); p.trace[1281] = __builtin_amdgcn_s_memrealtime(); }
-    for (int i = 0; i < NS - 1; ++i) issue();
-    wait_vmcnt_n<INFLIGHT>();
-    pp_barrier(); // e0: chunk 0 visible
-
-    // Barrier events e: chunk c is visible to all at e=2c, read by group A in (2c,2c+1) and by group B in
-    // (2c+1,2c+2); its ring slot is refilled (chunk c+NS) by A in (2c+2,..) and by B one interval later.
-    // Each group issues its LDS-DMA pieces in its own R phase, while its SIMD partner runs MFMAs.
-    //   A: R(reads, DMA issue) | bar(odd) | C(16 MFMA), wait | bar(even)
-    //   B:                R(reads, DMA issue), wait | bar(even) | C | bar(odd)
-    if (group) pp_barrier(); // e1: group B now runs half a period behind group A
-    int gchunk = 0;
-#define TR(pt) do { if (ABL == 9 && blockIdx.x == 0 && lane == 0 && gchunk >= 96 && gchunk < 112) p.trace[((gchunk - 96) * 8 + wave) * 10 + (pt)] = __builtin_amdgcn_s_memtime(); } while (0)
-    for (int tile = first_tile; tile < p.tile_end; tile += tstep) {
-        zero_acc();
-        for (int c = 0; c < nch; ++c, ++gchunk) {
-            TR(0);
-            if (p.tune & 2) __builtin_amdgcn_s_setprio(2);
-            if (ABL == 14) {
-                if (gchunk == 0) read_frags(smem + cs * STAGE, a_off, b_off, f);
-                issue();
-            } else if (p.tune & 4) {
-                issue();
-                read_frags(smem + cs * STAGE, a_off, b_off, f);
-            } else {
-                read_frags(smem + cs * STAGE, a_off, b_off, f);
-                issue();
-            }
-            cs = (cs == NS - 1) ? 0 : cs + 1;
-            if (p.tune & 2) __builtin_amdgcn_s_setprio(0);
-            TR(2);
-            if (!group && c == 1) maybe_flush(); // right after the even event that follows every tile's pushes
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            TR(3);
-            if (group) wait_vmcnt_n<INFLIGHT>(); // my pieces of the next chunk have landed (needed at the even event)
-            TR(4);
-            if (ABL != 15) pp_barrier();
-            TR(5);
-            if (group && c == 0) maybe_flush(); // same hardware event as group A's check
-            if (ABL == 1) { asm volatile("" ::"v"(f.a[0][0]), "v"(f.a[0][1]), "v"(f.a[1][0]), "v"(f.a[1][1])); asm volatile("" ::"v"(f.b[0][0]), "v"(f.b[0][1]), "v"(f.b[0][2]), "v"(f.b[0][3])); asm volatile("" ::"v"(f.b[1][0]), "v"(f.b[1][1]), "v"(f.b[1][2]), "v"(f.b[1][3])); }
-            else mma_chunk(f, acc, p.tune);
-            TR(7);
-            if (c == nch - 1) {
-                if (QUEUE) filter_tile(p, acc, tau, tile * BM + wm * 64 + 4 * hi, qbase, lane, qbuf, qcnt);
-                else filter_tile_direct(p, acc, tau, tile * BM + wm * 64 + 4 * hi, qbase);
-            }
-            if (!group) wait_vmcnt_n<INFLIGHT>();
-            TR(8);
-            if (ABL != 15) pp_barrier();
-            TR(9);
-        }
-    }
-#undef TR
-    if (!group) pp_barrier(); // pairs with group B's last odd event
-    if (ABL == 8 && blockIdx.x == 0 && tid == 0) { p.trace[1282] = __builtin_amdgcn_s_memtime(); p.trace[1283] = __builtin_amdgcn_s_memrealtime(); }
-
-    wait_vmcnt0();
-    if (QUEUE) {
-        __syncthreads();
-        flush_queue(p, qbuf, qcnt, *(volatile __attribute__((address_space(3))) unsigned *)qcnt, tid);
-    }
-}
-
-template <int WM, int WN, int NS, int ABL = 0>
-static int launch_scan_pp_t(const ScanParams &p, int grid, hipStream_t stream)
-{
-    constexpr int STAGE = (WM * 64 + WN * 128) * 64;
-    constexpr int LDS = NS * STAGE + (NS == 3 ? QCAP * 16 + 16 : 0);
-    static_assert(LDS <= 163840, "LDS budget");
-    static bool attr_done = false;
-    if (!attr_done) {
-        if (hipFuncSetAttribute((const void *)mips_scan_pp_kernel<WM, WN, NS, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_done = true;
-    }
-    hipLaunchKernelGGL((mips_scan_pp_kernel<WM, WN, NS, ABL>), dim3(grid), dim3(512), LDS, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-// depth: 3 (LDS survivor queue) or 4 (all LDS for the ring, survivors written directly)
-int mips_launch_scan_pp(int variant, int depth, const ScanParams &p, int grid, hipStream_t stream)
-{
-    switch (variant * 2 + (depth == 4)) {
-    case 0: return launch_scan_pp_t<2, 4, 3>(p, grid, stream);
-    case 1: return launch_scan_pp_t<2, 4, 4>(p, grid, stream);
-    case 2: return launch_scan_pp_t<4, 2, 3>(p, grid, stream);
-    case 3: return launch_scan_pp_t<4, 2, 4>(p, grid, stream);
-    case 4: return launch_scan_pp_t<8, 1, 3>(p, grid, stream);
-    case 5: return launch_scan_pp_t<8, 1, 4>(p, grid, stream);
-    }
-    return -1;
-}
-
-// ================================================================================================
-// v5 ("q8"): 128 rows x 512 queries per workgroup, every wave owns 64 queries and ALL 128 rows.
-// The query operand (80 % of the operand bytes) never touches LDS: each wave streams its private
-// B fragments from a fragment-tiled query image (L2 resident) straight into VGPRs with plain 1 KiB
-// coalesced global loads, double buffered one chunk ahead.  Only the index rows go through LDS
-// (one 1 KiB LDS-DMA piece per wave per chunk, 4-deep ring), which removes 4/5 of the LDS-DMA
-// instructions that bounded v1-v4 (measured: ~1 KiB per 30 cycles per CU).
-// q_frag layout: [chunk][wave 8][ks 2][ni 2][lane 64][16 B].
-// ================================================================================================
-#define NSE 4
-template <int ABL = 0>
-__global__ void __launch_bounds__(512) mips_scan_q8_kernel(ScanParams p)
-{
-    constexpr int BM = 128;
-    constexpr int E_STAGE = BM * 64; // 8 KiB
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    char *const qbuf = smem + NSE * E_STAGE;
-    unsigned *const qcnt = (unsigned *)(qbuf + QCAP * 16);
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int swz = (l31 >> 2) & 3;
-
-    const int first_tile = p.tile_begin + (int)blockIdx.x;
-    if (first_tile >= p.tile_end) return;
-    if (tid == 0) *qcnt = 0;
-
-    int a_off[2];
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) a_off[ks] = l31 * 64 + (((ks * 2 + hi) ^ swz) << 4);
-
-    float tau[2];
-#pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = wave * 64 + ni * 32 + l31;
-        tau[ni] = (q < p.n_q) ? p.tau[q] : __builtin_inff();
-    }
-    const unsigned qbase = wave * 64 + l31;
-
-    const int nch = p.nch;
-    const int tstep = (int)gridDim.x;
-    const int my_tiles = (p.tile_end - first_tile + tstep - 1) / tstep;
-    const int G = my_tiles * nch; // chunks this workgroup consumes
-
-    // E prefetch cursor (3 chunks ahead)
-    int pf_tile = first_tile, pf_c = 0, pf_stage = 0;
-    auto issue_e = [&]() {
-        const int t = pf_tile < p.tile_end ? pf_tile : first_tile;
-        if (ABL != 3) glds16(p.e_tiled + ((size_t)t * nch + pf_c) * STRIPE_CHUNK_BYTES + wave * 1024 + lane * 16, smem + pf_stage * E_STAGE + wave * 1024);
-        if (++pf_c == nch) { pf_c = 0; pf_tile += tstep; }
-        pf_stage = (pf_stage == NSE - 1) ? 0 : pf_stage + 1;
-    };
-    // this wave's B fragments of chunk c: 4 x 16 B per lane
-    const char *const qlane = p.q_tiled + (size_t)wave * 4096 + lane * 16;
-    // Loads hidden from hipcc's waitcnt bookkeeping (it would drain the whole queue at the first use across
-    // the loop back-edge): issued here, waited for by wait_q() one chunk later (cdna guide 5.7 form ii).
-    auto load_q = [&](int c, half8 (&b)[2][2]) {
-        const char *src = qlane + (size_t)c * 32768;
-        asm volatile("global_load_dwordx4 %0, %4, off\n\t"
-                     "global_load_dwordx4 %1, %4, off offset:1024\n\t"
-                     "global_load_dwordx4 %2, %4, off offset:2048\n\t"
-                     "global_load_dwordx4 %3, %4, off offset:3072"
-                     : "=&v"(b[0][0]), "=&v"(b[0][1]), "=&v"(b[1][0]), "=&v"(b[1][1])
-                     : "v"(src)
-                     : "memory");
-    };
-    // everything but the youngest VMEM op (the E piece issued after these loads) has returned
-    auto wait_q = [&](half8 (&b)[2][2]) {
-        asm volatile("s_waitcnt vmcnt(1)" : "+v"(b[0][0]), "+v"(b[0][1]), "+v"(b[1][0]), "+v"(b[1][1])::"memory");
-    };
-
-    floatx16 acc[4][2];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    };
-    zero_acc();
-
-    half8 b0[2][2], b1[2][2];
-    issue_e();
-    issue_e();
-    load_q(0, b0);
-    issue_e();
-
-    int cs = 0, c = 0, tile = first_tile;
-    // one chunk: B fragments in `bc`, prefetch the next chunk's into `bn`
-    auto step = [&](int g, half8 (&bc)[2][2], half8 (&bn)[2][2]) {
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        wait_q(bc); // my B fragments and (older) my E piece of this chunk have landed
-        pp_barrier();
-        if (c == 1) {
-            const unsigned n = *(volatile __attribute__((address_space(3))) unsigned *)qcnt;
-            if (n >= FLUSH_AT) {
-                flush_queue(p, qbuf, qcnt, n, tid);
-                __syncthreads();
-                if (tid == 0) *qcnt = 0;
-                __syncthreads();
-            }
-        }
-        int cn = c + 1 == nch ? 0 : c + 1;
-        load_q(cn, bn);
-        issue_e(); // chunk g+3 into the slot of chunk g-1
-        const char *sb = smem + cs * E_STAGE;
-        cs = (cs == NSE - 1) ? 0 : cs + 1;
-#pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            half8 a[4];
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi) a[mi] = *(const half8 *)(sb + a_off[ks] + mi * 2048);
-#pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
-                    acc[mi][ni] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[mi], bc[ks][ni], acc[mi][ni], 0, 0, 0);
-        }
-        if (c == nch - 1) {
-            // C layout: query = lane&31 (+32 ni), row = mi*32 + (r&3) + 8*(r>>2) + 4*hi
-            const int row0 = tile * BM + 4 * hi;
-            bool stored = false;
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                float m = acc[0][ni][0];
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
-                if (__builtin_amdgcn_ballot_w64(m >= tau[ni]) == 0) continue;
-                const unsigned q = qbase + ni * 32;
-#pragma unroll
-                for (int mi = 0; mi < 4; ++mi) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float v = acc[mi][ni][r];
-                        const int row = row0 + mi * 32 + (r & 3) + 8 * (r >> 2);
-                        const bool pass = (v >= tau[ni]) && (row < p.n_rows);
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
-                        if (mask == 0) continue;
-                        unsigned base = 0;
-                        if (lane == 0) base = atomicAdd(qcnt, (unsigned)__popcll(mask));
-                        base = __builtin_amdgcn_readfirstlane(base);
-                        if (pass) {
-                            const unsigned slot = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            if (slot < QCAP) {
-                                ((uint4 *)qbuf)[slot] = make_uint4(__float_as_uint(v), (unsigned)row, q, 0u);
-                            } else {
-                                const unsigned gs = atomicAdd(&p.count[q], 1u);
-                                if (gs < p.capq) p.cand[(size_t)q * p.capq + gs] = make_uint2(__float_as_uint(v), (unsigned)row);
-                                else atomicOr(&p.flags[q], 2u);
-                                stored = true;
-                            }
-                        }
-                    }
-                }
-            }
-            if (__builtin_amdgcn_ballot_w64(stored)) wait_vmcnt0(); // stores may retire out of order with loads
-            zero_acc();
-            tile += tstep;
-        }
-        c = cn;
-    };
-
-    int g = 0;
-    for (; g + 1 < G; g += 2) {
-        step(g, b0, b1);
-        step(g + 1, b1, b0);
-    }
-    if (g < G) step(g, b0, b1);
-
-    wait_vmcnt0();
-    __syncthreads();
-    flush_queue(p, qbuf, qcnt, *(volatile __attribute__((address_space(3))) unsigned *)qcnt, tid);
-}
-
-int mips_launch_scan_q8(int abl, const ScanParams &p, int grid, hipStream_t stream)
-{
-    constexpr int LDS = NSE * 8192 + QCAP * 16 + 16;
-    static bool attr_done[2] = {false, false};
-    const void *fn = abl == 3 ? (const void *)mips_scan_q8_kernel<3> : (const void *)mips_scan_q8_kernel<0>;
-    if (!attr_done[abl == 3]) {
-        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -3;
-        attr_done[abl == 3] = true;
-    }
-    if (abl == 3) hipLaunchKernelGGL((mips_scan_q8_kernel<3>), dim3(grid), dim3(512), LDS, stream, p);
-    else hipLaunchKernelGGL((mips_scan_q8_kernel<0>), dim3(grid), dim3(512), LDS, stream, p);
-    return hipGetLastError() == hipSuccess ? 0 : -3;
-}
-
-#endif // EMDR2_EXPERIMENTS
+#ifdef EMDR2_EXPERIMENTS   // schedule variants kept for tools/ only (`make exp`): not product code, not in this directory
+#include "../../tools/exp/mips_scan_variants.inc"
+#endif
 template <int WM, int WN, int MODE, int ABL = 0>
 static int launch_scan_t(const ScanParams &p, int grid, hipStream_t stream)
 {
@@ -774,22 +401,7 @@ static int launch_scan_t(const ScanParams &p, int grid, hipStream_t stream)
 }
 
 #ifdef EMDR2_EXPERIMENTS
-int mips_launch_scan_ablate(int abl, const ScanParams &p, int grid, hipStream_t stream)
-{
-    switch (abl) {
-    case 14: return launch_scan_pp_t<2, 4, 4, 14>(p, grid, stream);
-    case 15: return launch_scan_pp_t<2, 4, 4, 15>(p, grid, stream);
-    case 8: return launch_scan_pp_t<2, 4, 4, 8>(p, grid, stream);
-    case 9: return launch_scan_pp_t<2, 4, 4, 9>(p, grid, stream);
-    case 11: return launch_scan_pp_t<2, 4, 4, 1>(p, grid, stream);
-    case 13: return launch_scan_pp_t<2, 4, 4, 3>(p, grid, stream);
-    case 4: return launch_scan_t<2, 4, 0, 4>(p, grid, stream);
-    case 1: return launch_scan_t<2, 4, 0, 1>(p, grid, stream);
-    case 2: return launch_scan_t<2, 4, 0, 2>(p, grid, stream);
-    case 3: return launch_scan_t<2, 4, 0, 3>(p, grid, stream);
-    }
-    return -1;
-}
+#include "../../tools/exp/mips_scan_variants_launch.inc"
 #endif
 
 int mips_launch_scan(int variant, int mode, const ScanParams &p, int grid, hipStream_t stream)

@@ -26,8 +26,9 @@ namespace {
 
 #define S8_BUF 65536
 #define S8_SLOT 16384
-#define S8_QCAP 2040              // survivor queue entries (16 B each); the counter sits behind them
-#define S8_FLUSH_AT 1024
+#define S8_QCAP 2040              // survivor queue entries (16 B each); the counters sit behind them
+#define S8_WCAP 255               // ... in eight wave-private regions: a wave reserves slots by adding to its OWN count, no LDS atomic, no round trip
+#define S8_FLUSH_AT 128           // flush when some wave's region is half full
 
 struct Scan8Params {
     ScanParams s;
@@ -39,14 +40,26 @@ struct Scan8Params {
     unsigned *prog;               // progress counters, one per pair of workgroups that share row tiles, 64 uints apart (zeroed by the caller), or nullptr
 };
 
-__device__ __forceinline__ void s8_flush(const ScanParams &p, const char *qbuf, unsigned n, int tid)
+// A survivor's slot in query q's candidate set.  r04: one sub-list per XCD (ScanParams.cand8 / count8) and an atomic of WORKGROUP scope: it is
+// performed by this XCD's L2 on a line no other XCD touches during the launch, instead of going out to the memory side like the agent-scope
+// atomic on ONE counter per query did (eight L2s are not coherent among themselves: ~0.2 us each, 380,000 of them in the segment right after
+// the dense one = 80 of its 215 us).  The select that follows a segment reads the main list and the eight sub-lists (mips_aux.hip).
+__device__ __forceinline__ void s8_append(const ScanParams &p, unsigned xcc, unsigned q, unsigned score_bits, unsigned row)
 {
-    const unsigned m = n < S8_QCAP ? n : S8_QCAP;
-    for (unsigned i = tid; i < m; i += 512) {
-        const uint4 e = ((const uint4 *)qbuf)[i];
-        const unsigned slot = atomicAdd(&p.count[e.z], 1u);
-        if (slot < p.capq) p.cand[(size_t)e.z * p.capq + slot] = make_uint2(e.x, e.y);
-        else atomicOr(&p.flags[e.z], 2u);
+    const unsigned slot = __hip_atomic_fetch_add(&p.count8[xcc * 512 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (slot < SUBCAP) p.cand8[((size_t)q * 8 + xcc) * SUBCAP + slot] = make_uint2(score_bits, row);
+    // (past the end: the count keeps growing and the select flags the query for the exact fallback)
+}
+
+// queue -> candidate sub-lists; cnt[w] = entries in wave w's region (all 512 threads take part: thread t drains region t >> 6)
+__device__ __forceinline__ void s8_flush(const ScanParams &p, const char *qbuf, const unsigned *cnt, int tid, unsigned xcc)
+{
+    const int region = tid >> 6;
+    unsigned m = ((const volatile __attribute__((address_space(3))) unsigned *)cnt)[region];
+    if (m > S8_WCAP) m = S8_WCAP;
+    for (unsigned i = tid & 63; i < m; i += 64) {
+        const uint4 e = ((const uint4 *)qbuf)[region * S8_WCAP + i];
+        s8_append(p, xcc, e.z, e.x, e.y);
     }
 }
 
@@ -70,8 +83,13 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     if (first >= seq_hi) return;
     const int my_count = (seq_hi - first + wg_per_xcd - 1) / wg_per_xcd;
     const int KT = p.nch >> 1;                                // K-tiles of 64 = pairs of 32-wide chunks; even (host)
-    unsigned *const flagw = qcnt + 4;                          // LDS landing word of the partner-progress DMA
-    if (tid == 0) { *qcnt = 0; *flagw = 0; }
+    unsigned *const flagw = qcnt + 8;                          // LDS landing word of the partner-progress DMA (behind the eight region counts)
+    if (tid < 8) qcnt[tid] = 0;
+    if (tid == 0) *flagw = 0;
+    unsigned wq = 0;                                           // entries in this wave's queue region (wave-uniform)
+    // the XCD this workgroup really runs on (HW_REG_XCC_ID: id 20, bits 0..3), not the one its block id suggests: the sub-list protocol is
+    // only correct if all appenders of a sub-list share an L2
+    const unsigned xcc = __builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 7u;
     // the workgroups of an XCD stride the sequence by an even count (host) and `per` is even: a workgroup keeps ONE query half for all its items,
     // so its thresholds are loaded once (a load in the filter would wait out the whole DMA queue: vmcnt is in order)
     const int hq = P.halves == 2 ? first & 1 : 0;
@@ -172,17 +190,20 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     // Queue high-water check.  Both wave halves run it in the SAME barrier interval -- the first one after all pushes of the finished item
     // (leading half: right behind the first barrier of the next item; trailing half: right behind its seam barrier) -- so the decision is
     // uniform, and the two barriers inside pair up half against half.
-#define S8_MAYBE_FLUSH()                                                                                                                  \
-    do {                                                                                                                                  \
-        const unsigned n_ = *(volatile __attribute__((address_space(3))) unsigned *)qcnt;                                                  \
-        if (n_ >= S8_FLUSH_AT) {                                                                                                          \
-            s8_flush(p, qbuf, n_, tid);                                                                                                   \
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                                              \
-            S8_BARRIER();                                                                                                                 \
-            if (tid == 0) *qcnt = 0;                                                                                                      \
-            S8_BARRIER();                                                                                                                 \
-        }                                                                                                                                 \
-    } while (0)
+    auto maybe_flush = [&]() {
+        unsigned n_ = 0;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) n_ = max(n_, ((const volatile __attribute__((address_space(3))) unsigned *)qcnt)[w]);
+        if (n_ >= S8_FLUSH_AT) {
+            s8_flush(p, qbuf, qcnt, tid, xcc);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            S8_BARRIER();
+            if (tid < 8) qcnt[tid] = 0;
+            wq = 0;
+            S8_BARRIER();
+        }
+    };
+#define S8_MAYBE_FLUSH() maybe_flush()
 
     // ---- partner coupling.  The two workgroups that take the two query halves of the same row tiles (slots 2j, 2j + 1 of one XCD) should read
     // the index rows within the L2's residency of each other (~10 us of streaming); nothing else couples them (a miss does not slow the
@@ -273,6 +294,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const int e31 = elane & 31, ehi = elane >> 5;
         const int row_w = tile * 256 + wr * 128 + 4 * ehi;    // + 64 mh + 32 f + (r & 3) + 8 (r >> 2)
+        const bool tail = (tile + 1) * 256 > p.n_rows;          // only the shard's last tile has rows that do not exist
         bool stored = false;
 #pragma unroll
         for (int ni = 0; ni < 2; ++ni) {
@@ -286,31 +308,33 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
                 if (__builtin_amdgcn_ballot_w64(m >= tau) == 0) continue;          // the common case
+                // a block with survivors.  Slots come out of this wave's OWN queue region: the reservation is a scalar add (r03: a ballot, an LDS
+                // atomic by lane 0 and a readfirstlane round trip per register that held a survivor -- most of the filter's cost while the
+                // threshold is still loose); registers without a survivor cost a compare and a scalar branch.
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float v = acc[mi][ni][r];
                     const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    const bool pass = (v >= tau) && (row < p.n_rows);
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64(pass);
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
                     if (mask == 0) continue;
-                    unsigned base = 0;
-                    if (elane == 0) base = atomicAdd(qcnt, (unsigned)__popcll(mask));
-                    base = __builtin_amdgcn_readfirstlane(base);
-                    if (pass) {
-                        const unsigned slot_ = base + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        if (slot_ < S8_QCAP) {
-                            ((uint4 *)qbuf)[slot_] = make_uint4(__float_as_uint(v), (unsigned)row, q, 0u);
-                        } else {                                                   // queue full: straight to the candidate buffer
-                            const unsigned g = atomicAdd(&p.count[q], 1u);
-                            if (g < p.capq) p.cand[(size_t)q * p.capq + g] = make_uint2(__float_as_uint(v), (unsigned)row);
-                            else atomicOr(&p.flags[q], 2u);
+                    if ((mask >> elane) & 1ull) {
+                        const unsigned mine = wq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (mine < S8_WCAP) {                                      // (two writes: no aligned register quad to assemble)
+                            ((uint2 *)qbuf)[2 * (wave * S8_WCAP + mine)] = make_uint2(__float_as_uint(v), (unsigned)row);
+                            ((unsigned *)qbuf)[4 * (wave * S8_WCAP + mine) + 2] = q;
+                        } else {                                                   // queue region full: straight to the sub-list
+                            s8_append(p, xcc, q, __float_as_uint(v), (unsigned)row);
                             stored = true;
                         }
                     }
+                    wq += (unsigned)__popcll(mask);
                 }
             }
         }
         if (__builtin_amdgcn_ballot_w64(stored)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (wq > S8_WCAP) wq = S8_WCAP;                        // (the overflow went straight to the candidate buffers)
+        if (elane == 0) qcnt[wave] = wq;                       // published before the barrier behind which both halves look at the counts
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (wr == 1) {
             S8_BARRIER();
             if (ti + 1 < my_count) S8_MAYBE_FLUSH();
@@ -320,7 +344,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     if (prog && tid == 0) atomicAdd(prog, 1u << 20);          // done: the partner stops pacing itself against this workgroup
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // speculative half-tiles past the end of the stream
     S8_BARRIER();
-    s8_flush(p, qbuf, *(volatile __attribute__((address_space(3))) unsigned *)qcnt, tid);
+    s8_flush(p, qbuf, qcnt, tid, xcc);
 }
 
 } // namespace
@@ -328,7 +352,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
 // Filter scan (mode 0) of rows [row_begin, row_end) for a query image of `bn` = 256 or 512 rows; -4 = not covered (the caller uses mips_scan.hip)
 int mips_launch_scan8(const ScanParams &p, int bn, int64_t row_begin, int64_t row_end, int cus, unsigned *prog, hipStream_t stream)
 {
-    if ((bn != 256 && bn != 512) || (p.nch & 3) || p.nch < 4 || (row_begin & 255) || row_end <= row_begin) return -4;
+    if ((bn != 256 && bn != 512) || (p.nch & 3) || p.nch < 4 || (row_begin & 255) || row_end <= row_begin || !p.cand8 || !p.count8) return -4;
     Scan8Params P;
     P.s = p;
     P.prog = prog;
