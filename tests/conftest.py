@@ -28,3 +28,19 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True, scope="module")
+def _give_cached_hbm_back_after_each_module():
+    """The benchmark-shape tests leave > 200 GB in this process's caching allocator; tests that start OTHER processes on the same GPU
+    (tests/test_dist_gpu.py: the plain `bench.py --gpus 2` command) need it back."""
+    yield
+    if "torch" in sys.modules:
+        import gc
+        import torch
+        if torch.cuda.is_available() and torch.cuda.is_initialized():
+            from emdr2_amd.model import kernels as K
+            K.GRAD_SINK = None
+            K.ATTN_STASH.store.clear()
+            gc.collect()
+            torch.cuda.empty_cache()
