@@ -7,7 +7,7 @@ import csv, glob, json, os, sys
 
 args = sys.argv[1:]
 out = args[args.index("--out") + 1]
-dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] != "--out")]
+dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] not in ("--out", "--growth"))]
 res = {"kernel": None}
 for d in dirs:
     # counter_collection.csv carries kernel name, timestamps and one row per (dispatch, counter); its dispatch ids are NOT the kernel trace's
@@ -21,7 +21,21 @@ for d in dirs:
     res.setdefault("scan_last_segment_launch_ns", {"n": len(ns), "avg": sum(v for _, v in ns) / len(ns), "min": min(v for _, v in ns), "max": max(v for _, v in ns)})
     for r in big:
         res.setdefault(r["Counter_Name"] + "_KB_last_segment_launch", []).append(float(r["Counter_Value"]))
-rows, nq, dim = 18918172, 512, 768
+# rows of the last segment: the index minus what the dense segment and the growing filter segments before it covered (mips_api.hip: first
+# segment 8,192 rows, boundaries x 8 (r04; x 16 before), a tail shorter than half the scanned prefix joins the previous segment)
+n_rows, seg0, growth, nq, dim = 21015324, 8192, (int(args[args.index("--growth") + 1]) if "--growth" in args else 8), 512, 768
+done, seg_end, nxt = 0, seg0, seg0 * growth
+while True:
+    start = done
+    done = seg_end
+    if done >= n_rows:
+        break
+    seg_end = min(nxt, n_rows)
+    if n_rows - seg_end < seg_end // 2:
+        seg_end = n_rows
+    nxt *= growth
+rows = n_rows - start
+res["rows_last_segment"] = rows
 res["algorithmic_bytes_last_segment"] = rows * dim * 2          # the index rows of the segment, each read once
 f = res.get("FETCH_SIZE_KB_last_segment_launch"); w = res.get("WRITE_SIZE_KB_last_segment_launch")
 if f:
