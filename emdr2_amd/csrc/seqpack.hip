@@ -119,7 +119,14 @@ __global__ void __launch_bounds__(256) scatter_rows_kernel(const uint4 *in, cons
 extern "C" int emdr2_seq_lengths(const int64_t *ids, int n, int S, int32_t *cu, int64_t *totals, void *stream)
 {
     if (!ids || !cu || !totals || n < 1 || S < 1) return -1;
-    if (n > 16000) return -4;                                                    // the lengths live in LDS (64 KB)
+    if (n > 38000) return -4;                                                    // the lengths live in LDS: 152 of the 160 KB (B = 256 at top-k 100 is 25,600)
+    if (n > 16000) {                                                             // past the 64 KB a kernel gets without asking
+        static bool attr_done = false;
+        if (!attr_done) {
+            if (hipFuncSetAttribute((const void *)seq_lengths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 38000 * (int)sizeof(int)) != hipSuccess) return -3;
+            attr_done = true;
+        }
+    }
     hipLaunchKernelGGL(seq_len_kernel, dim3((unsigned)(n + 15) / 16), dim3(1024), 0, (hipStream_t)stream, (const long long *)ids, n, S, (int *)cu);
     hipLaunchKernelGGL(seq_lengths_kernel, dim3(1), dim3(1024), (size_t)n * sizeof(int), (hipStream_t)stream, n, (int *)cu, (long long *)totals);
     return LAUNCH_OK();

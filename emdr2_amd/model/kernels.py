@@ -230,11 +230,25 @@ def _linear_grads_into(dy2, x2, weight, bias):
 
 # ---- one input, many linear consumers: the input gradient is summed by the consumers' own GEMMs --------------------------------
 class _FanInState(object):
-    def __init__(self):
-        self.acc = None
+    def __init__(self, node, numel):
+        import weakref
+        self.acc, self.node, self.numel = None, weakref.ref(node), numel
 
 
-FANIN = {}      # data_ptr of a tensor that went through `fan_in` -> its gradient accumulator (lives from that forward to its backward)
+class _FanInTable(dict):
+    """data_ptr of a tensor that went through `fan_in` -> its gradient accumulator (lives from that forward to its backward).  An entry
+    whose graph has gone away without a backward (its autograd node is dead) is void: the allocator may have handed that address to another
+    linear layer's input, whose gradient must not be swallowed -- `live` drops such entries instead of returning them."""
+
+    def live(self, x2):
+        st = self.get(x2.data_ptr())
+        if st is not None and (st.node() is None or st.numel != x2.numel()):
+            del self[x2.data_ptr()]
+            return None
+        return st
+
+
+FANIN = _FanInTable()
 
 
 class FanInFn(torch.autograd.Function):
@@ -247,7 +261,7 @@ class FanInFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         ctx.key = x.data_ptr()
-        FANIN[ctx.key] = _FanInState()
+        FANIN[ctx.key] = _FanInState(ctx, x.numel())
         ctx.set_materialize_grads(False)
         return x.view_as(x)
 
@@ -444,7 +458,7 @@ class LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             wt = w_bf16_t(weight) if ctx.row_perm is None else WEIGHTS.get(weight, "perm_t", lambda: transpose(w_bf16_perm(weight, ctx.row_perm)))
-            shared = FANIN.get(x2.data_ptr())
+            shared = FANIN.live(x2)
             if shared is None:
                 dx = matmul_nt(dy2, wt).reshape(ctx.shp)                                  # [M,N] x [K,N]^T
             elif shared.acc is None:

@@ -364,23 +364,26 @@ class FlatAdam(object):
         if not active:
             return 0.0
         self._gsq.zero_()
-        saved = [(p, p.data.clone()) for p in getattr(self, "inactive", [])]      # untouched by the update, like `grad is None` in apex / torch
+        # parameters without a gradient this step are untouched by the update -- master AND both moments -- like `grad is None` in apex / torch
+        saved = [(p, p.data.clone()) + tuple(t.clone() for t in self._moments(p)) for p in getattr(self, "inactive", [])]
         for b in active:
             _native.check(lib.emdr2_sumsq_f32(b["grad"].data_ptr(), b["n"], self._gsq.data_ptr(), self._scratch.data_ptr(), sp), "sumsq")
         for b in active:
             _native.check(lib.emdr2_adam_step_flat(b["master"].data_ptr(), b["grad"].data_ptr(), b["m"].data_ptr(), b["v"].data_ptr(), b["work"].data_ptr(),
                                                    b["n"], b["split"], lr, self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
                                                    self._gsq.data_ptr(), self.clip_grad, sp), "adam_step_flat")
-        for p, old in saved:
+        for p, old, m_old, v_old in saved:
             p.data.copy_(old)
-        self.launches_last_step += 1 + 2 * len(active) + 2 * len(saved)
+            m, v = self._moments(p)
+            m.copy_(m_old); v.copy_(v_old)
+        self.launches_last_step += 1 + 2 * len(active) + 6 * len(saved)
         self.optimizer_launches = self.launches_last_step
         self.launches_last_step = 0
         self._stale = True                    # the gradient buckets are spent: the next contribution starts a new step if zero_grad() does not
         from emdr2_amd.model import kernels
         kernels.WEIGHTS.invalidate()          # drops the derived forms (transposed / row-permuted copies) of every weight ...
         self._stamp_all()                     # ... while the bf16 working copies were just written by the Adam kernel itself
-        for p, old in saved:                  # restored masters: their working copies were overwritten by the kernel
+        for p, *_ in saved:                   # restored masters: their working copies were overwritten by the kernel
             p.__dict__["_emdr2_work_stamp"] = None
         kernels.DROPOUT.step = self.step_count
         return self._gsq

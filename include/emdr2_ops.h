@@ -103,7 +103,7 @@ int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn,
  * Layout: sequence i keeps its first len[i] tokens, len[i] = 1 + index of its last non-pad (id != 0) token (S for an all-pad row), and
  * owns rows [cu[i], cu[i+1]) of a [rows, ...] tensor; cu = exclusive prefix sum of len (int32 [n+1]).
  *
- * emdr2_seq_lengths: cu from ids [n, S]; totals[0] = cu[n], totals[1] = sum len^2, totals[2] = max len (int64 [3], device).  n <= 16000.
+ * emdr2_seq_lengths: cu from ids [n, S]; totals[0] = cu[n], totals[1] = sum len^2, totals[2] = max len (int64 [3], device).  n <= 38000 (the lengths are scanned in LDS).
  * emdr2_seq_pack_ids: rowmap[t] (int32 [rows_padded]) = dense row i*S+pos of packed row t (-1 for t >= total: tail rows up to a GEMM-friendly
  *   multiple), inverse[i*S+pos] (int32 [n*S]) = packed row or -1, ids_packed / types_packed (int64 [rows_padded], 0 in the tail).
  * emdr2_gather_rows: out[r, :] = map[r] >= 0 ? in[map[r], :] : 0 (bf16 rows of H, H % 8 == 0) -- dense -> packed with rowmap, packed -> dense

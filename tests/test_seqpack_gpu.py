@@ -296,3 +296,16 @@ def test_emdr2_step_packed_equals_dense(recompute):
     gmax = max(float(g.abs().max()) for g in g_d.values())
     worst = max((float((g_p[k] - g_d[k]).abs().max()) / max(float(g_d[k].abs().max()), 1e-2 * gmax), k) for k in g_d)
     assert worst[0] < 3e-2, worst
+
+
+def test_twenty_five_thousand_sequences_pack_like_the_reference_loop():
+    """B = 256 questions at top-k 100 is 25,600 sequences per stack (the length scan used to stop at 16,000)."""
+    from emdr2_amd.model import kernels as K
+    n, S = 25600, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    lens = torch.randint(1, S + 1, (n,), generator=g, device="cuda")
+    ids = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).long() * 9
+    seqs = K.PackedSeqs(ids)
+    cu = torch.zeros(n + 1, dtype=torch.int64, device="cuda"); cu[1:] = torch.cumsum(lens, 0)
+    assert torch.equal(seqs.cu.long(), cu) and seqs.total == int(lens.sum()) and seqs.max_len == int(lens.max())
+    assert seqs.pairs == int((lens.long() ** 2).sum())
