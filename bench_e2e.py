@@ -127,45 +127,13 @@ def setup(args, rank, world, index=None, topk=50):
         return dict(uid=-torch.arange(1, B + 1, device="cuda"), q=q, types=torch.zeros_like(q), qlen=qlen.to(torch.int64), dec=dec,
                     labels=labels, mask=(labels != 0).float())
 
-    plan = {"keep": 0, "reader": 0, "context": 0, "thinned": 0}         # the retention plan in force (run() fills it in)
+    from emdr2_amd.training import RetentionGuard
+    # the retention plan in force (run() fills it in) and the all-ranks-together recovery from a step that runs out of HBM
+    guard = RetentionGuard(model, opt, forward_progress=lambda: retr.searches)
+    plan = guard.plan
 
     def step():
-        """One training step; a step that runs out of HBM is given up ON ALL RANKS TOGETHER and run again: the rank that failed
-        completes the step's gradient collectives through FlatAdam.abort_step(), its peers learn of it in finish() (StepAborted), and since
-        `attempt` and the plan are then the same everywhere, every rank frees / thins in the same way and re-enters the same collectives."""
-        import gc
-        from emdr2_amd.training import StepAborted
-        for attempt in range(6):
-            searched = retr.searches
-            try:
-                return step_once()
-            except torch.cuda.OutOfMemoryError:
-                if world > 1 and retr.searches == searched:
-                    raise                                                 # before the forward's own all-gathers completed: peers cannot be told
-                opt.abort_step()
-            except StepAborted:
-                pass
-            opt.zero_grad()
-            gc.collect()
-            torch.cuda.empty_cache()                                      # first: allocator fragmentation -- give the blocks back, same step again
-            oom_retries[0] += 1
-            if attempt >= 1:
-                # it really does not fit any more: the packed stacks' (sticky) row capacities grow by 16,384-row steps while new maxima
-                # of real tokens keep arriving (the first tens of steps), and every retained tensor grows with them.  Retain less.
-                if plan["context"] > 0:
-                    plan["context"] = max(0, plan["context"] - 2)
-                elif plan["keep"] > 0:
-                    plan["keep"] -= 1
-                elif plan["reader"] > 0:
-                    plan["reader"] = max(0, plan["reader"] - 2)
-                else:
-                    raise torch.cuda.OutOfMemoryError("the step does not fit with the reference's full per-layer recompute either")
-                plan["thinned"] += 1
-                model.set_recompute_keep_last(plan["keep"])
-                model.set_selective_retention(plan["reader"], plan["context"], args.layers if plan["context"] else 0)
-        return step_once()
-
-    oom_retries = [0]
+        return guard.run(step_once)
 
     inject = tuple(int(v) for v in os.environ.get("EMDR2_BENCH_INJECT_OOM", "-1,-1").split(","))    # "rank,call": dry-run hook of the tests
     calls = [0]
@@ -186,7 +154,7 @@ def setup(args, rank, world, index=None, topk=50):
         sched.step()
         return loss
 
-    return types.SimpleNamespace(make_batch=make_batch, retriever=retr, sched=sched, plan=plan, oom_retries=oom_retries, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(make_batch=make_batch, retriever=retr, sched=sched, plan=plan, guard=guard, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
@@ -261,7 +229,7 @@ def run(ctx, steps, warmup, world):
         # plan is thinned out (context tower first, then half of the reader layers, then the reference's full recompute)
         # (a plan also counts as too tight when the caching allocator had to give blocks back to the driver and ask again during the trial
         # step -- `num_alloc_retries` -- : such a step runs, but at 1.2-1.3 x the time)
-        retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0)) + ctx.oom_retries[0]
+        retries = lambda: int(torch.cuda.memory_stats().get("num_alloc_retries", 0)) + ctx.guard.reruns
 
         def any_rank(flag):                                  # every rank takes the same branch below
             if world == 1:
@@ -271,9 +239,7 @@ def run(ctx, steps, warmup, world):
             return bool(int(t.item()))
         for plan in ((keep, sel_r, sel_c), (0, sel_r, max(sel_c - 3, 0)), (0, sel_r, 0), (0, sel_r // 2, 0), (0, 0, 0)):
             keep, sel_r, sel_c = plan
-            ctx.plan.update(keep=keep, reader=sel_r, context=sel_c)
-            ctx.model.set_recompute_keep_last(keep)
-            ctx.model.set_selective_retention(sel_r, sel_c, ctx.layers if sel_c else 0)
+            ctx.guard.set(keep, sel_r, sel_c, ctx.layers if sel_c else 0)
             torch.cuda.empty_cache()                         # blocks cached for the previous retention pattern do not fit the new one
             before = retries()
             loss = ctx.step()                                # (an allocation failure inside is handled there, by all ranks together, and counted)
@@ -357,7 +323,7 @@ def run(ctx, steps, warmup, world):
                    "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
                                            ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
                                             "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),
-                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.oom_retries[0], "retention_thinned_after_out_of_memory": ctx.plan["thinned"],
+                   "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.guard.reruns, "retention_thinned_after_out_of_memory": ctx.plan["thinned"],
                    "timed_region_reruns_after_allocator_retry": timed_reruns,
                    "ms_per_step_full_recompute": ctx.full_recompute_ms,      # one step timed before the switch (None when nothing is kept)
                    "loss": float(loss.detach()), "replica_parameter_checksums": replicas,
@@ -434,7 +400,9 @@ def cpu_baseline_model(seconds=12.0, layers=12, threads=0):
     return {"value": 1.0 / (per * scale), "unit": "steps/s", "cores": cores, "kind": "port",
             "sample": "%d step(s) of the fp32 oracle (forward + loss + autograd backward, Adam excluded) at B=%d, K=%d, S_ret %d, S %d, L %d, "
                       "%d of 12 layers per stack, torch CPU, %d threads: %.2f s/step (first, untimed: %.2f s); scaled x%.0f by dense-GEMM flops to "
-                      "B=64, K=50" % (reps, B, K, S_ret, S, L, layers, cores, per, t_first, scale)}
+                      "B=64, K=50.  BASELINE configs[0] AS WRITTEN (10,000-row index, B = 8, K = 50, fp32) measured once, not scaled: 477 s per step "
+                      "on 64 host threads (profiles/r03_config0.json; its forward alone 376 s on the 8 cores of the build container, "
+                      "tests/golden/gen_config0_golden.py)" % (reps, B, K, S_ret, S, L, layers, cores, per, t_first, scale)}
 
 
 def main():

@@ -35,19 +35,29 @@ def _cross_entropy_forward_step(batch, model, eos_id):
     return net_loss, {'lm_loss': stats['lm_loss'], 'retriever_loss': stats['retriever_loss']}
 
 
-def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler, eos_id, dp_group=None):
-    """megatron/training.py:202-230 without the fp16 machinery (bf16 needs no loss scale / overflow skip)."""
+def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler, eos_id, dp_group=None, guard=None):
+    """megatron/training.py:202-230 without the fp16 machinery (bf16 needs no loss scale / overflow skip).  `guard` (training.RetentionGuard,
+    built when --recompute-keep-last-layers / --selective-retention-layers ask for activations to be kept): a step that runs out of HBM is
+    run again on all ranks together, with a thinner retention plan if need be, instead of ending the job."""
     from emdr2_amd.model import kernels
-    optimizer.zero_grad()
-    sink = kernels.GRAD_SINK
-    if sink is not None and sink is not optimizer:
-        sink.begin_step()
-    loss, loss_reduced = forward_step_func(data_iterator, model, eos_id)
-    loss.backward()
-    if sink is not None:
-        sink.finish()                                # buckets were all-reduced (bf16, pre-divided) while the backward ran
-    else:
-        allreduce_gradients(model, dp_group)
+    try:
+        batch = next(data_iterator)                  # fetched once: a re-run of the step sees the same batch
+    except TypeError:
+        batch = data_iterator
+
+    def step_once():
+        optimizer.zero_grad()
+        sink = kernels.GRAD_SINK
+        if sink is not None and sink is not optimizer:
+            sink.begin_step()
+        loss, loss_reduced = forward_step_func(batch, model, eos_id)
+        loss.backward()
+        if sink is not None:
+            sink.finish()                            # buckets were all-reduced (bf16, pre-divided) while the backward ran
+        else:
+            allreduce_gradients(model, dp_group)
+        return loss_reduced
+    loss_reduced = guard.run(step_once) if guard is not None else step_once()
     # the reference steps the optimizer with the rate its scheduler set at the END of the previous iteration (training.py:223-228,
     # learning_rates.py:73-80): step n runs at lr(n - 1), so the very first update of a warm-up schedule has lr 0
     optimizer.step(lr=lr_scheduler.get_lr())
@@ -189,6 +199,14 @@ def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_o
     boundary replaces the NEW_INDEX_READY / NEW_CHKPT_READY handshake and the reload from disk)."""
     args = get_args()
     model.train()
+    guard = None
+    sel = [int(v) for v in str(getattr(args, "selective_retention_layers", "0,0,0")).split(",")] + [0, 0, 0]
+    keep = int(getattr(args, "recompute_keep_last_layers", 0) or 0)
+    if keep or any(sel[:3]):
+        from emdr2_amd.training import RetentionGuard
+        retr = getattr(model, "evidence_retriever", None)
+        guard = RetentionGuard(model, optimizer, keep=keep, reader=sel[0], context=sel[1], query=sel[2],
+                               forward_progress=(lambda: getattr(retr, "searches", 0)) if retr is not None else None, log=print_rank_0)
     start_epoch = args.iteration // args.train_iters_per_epoch
     start_iteration = args.iteration % args.train_iters_per_epoch
     iteration = args.iteration
@@ -202,7 +220,7 @@ def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_o
             start_iteration = 0
             if indexer is not None:
                 indexer.pump()
-            losses = train_step(forward_step, batch, model, optimizer, lr_scheduler, eos_id)
+            losses = train_step(forward_step, batch, model, optimizer, lr_scheduler, eos_id, guard=guard)
             iteration += 1
             if indexer is not None and indexer.maybe_swap(iteration):
                 print_rank_0("Training Group: MIPS Index Updated at iteration {}".format(iteration))

@@ -408,3 +408,77 @@ class FlatAdam(object):
             m.copy_(st['exp_avg']); v.copy_(st['exp_avg_sq'])
         from emdr2_amd.model import kernels
         kernels.DROPOUT.step = self.step_count
+
+
+class RetentionGuard(object):
+    """Runs a training step under the activation-retention plan of an EMDR2Model and keeps it running when the plan stops fitting.
+
+    The plan -- `keep` reader-encoder layers whole, `reader` / `context` / `query` encoder layers with selective retention
+    (EMDR2Model.set_recompute_keep_last / set_selective_retention; everything else is re-run per layer like the reference's
+    --checkpoint-activations) -- is sized for the first steps; packed token counts, and with them every retained tensor, still grow a little
+    over the first tens of steps.  A step that runs out of HBM is given up ON ALL RANKS TOGETHER: the rank that failed completes the step's
+    gradient collectives (FlatAdam.abort_step), its peers learn of it in finish() (StepAborted), everybody frees its cached blocks and runs
+    the same step again; a second failure thins the plan (context tower first, then kept layers, then the reader's selective layers) by
+    the same rule on every rank.  `forward_progress()` is a counter that moves once the forward's own all-gathers (the retriever's) are
+    behind this rank -- before that point of an attempt its peers cannot be told and the failure is raised.  Used by bench_e2e.py and by
+    the training task."""
+
+    def __init__(self, model, optimizer, keep=0, reader=0, context=0, query=0, forward_progress=None, log=None):
+        self.model, self.opt = model, optimizer
+        self.plan = {"keep": int(keep), "reader": int(reader), "context": int(context), "query": int(query), "thinned": 0}
+        self.reruns = 0
+        self.forward_progress = forward_progress
+        self.log = log or (lambda msg: None)
+        self.apply()
+
+    def apply(self):
+        self.model.set_recompute_keep_last(self.plan["keep"])
+        self.model.set_selective_retention(self.plan["reader"], self.plan["context"], self.plan["query"])
+
+    def set(self, keep, reader, context, query=None):
+        self.plan.update(keep=int(keep), reader=int(reader), context=int(context))
+        if query is not None:
+            self.plan["query"] = int(query)
+        self.apply()
+
+    def thin(self):
+        p = self.plan
+        if p["context"] > 0:
+            p["context"] = max(0, p["context"] - 2)
+            if p["context"] == 0:
+                p["query"] = 0
+        elif p["keep"] > 0:
+            p["keep"] -= 1
+        elif p["reader"] > 0:
+            p["reader"] = max(0, p["reader"] - 2)
+        else:
+            return False
+        p["thinned"] += 1
+        self.apply()
+        self.log("retention plan thinned after an allocation failure: %s" % {k: v for k, v in p.items() if k != "thinned"})
+        return True
+
+    def run(self, step_once):
+        import gc
+        world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
+        for attempt in range(8):
+            mark = self.forward_progress() if self.forward_progress else None
+            try:
+                return step_once()
+            except torch.cuda.OutOfMemoryError:
+                if world > 1 and self.forward_progress and self.forward_progress() == mark:
+                    raise
+                abort = getattr(self.opt, "abort_step", None)
+                if abort is not None:
+                    abort()
+                elif world > 1:
+                    raise                                          # (an optimizer without the abort protocol cannot take its peers along)
+            except StepAborted:
+                pass
+            self.opt.zero_grad()
+            gc.collect()
+            torch.cuda.empty_cache()                               # first: allocator fragmentation -- give the blocks back, same step again
+            self.reruns += 1
+            if attempt >= 1 and not self.thin():
+                raise torch.cuda.OutOfMemoryError("the step does not fit with the reference's full per-layer recompute either")
+        return step_once()

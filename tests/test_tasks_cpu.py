@@ -2,6 +2,7 @@
 import os
 
 import numpy as np
+import pytest
 import torch
 
 GOLD = os.path.join(os.path.dirname(__file__), "golden")
@@ -160,3 +161,38 @@ def test_weight_decay_predicate_reproduces_the_reference_groups():
     assert len(every) == len(set(every)) == 130 and ref["no_weight_decay_value"] == 0.0
     assert [n for n in every if FlatAdam.is_no_decay(n)] == ref["no_weight_decay"]
     assert [n for n in every if not FlatAdam.is_no_decay(n)] == ref["weight_decay"]
+
+
+def test_retention_guard_reruns_then_thins_the_plan_in_a_fixed_order():
+    """training.RetentionGuard (bench_e2e.py and the training task): a step that runs out of HBM is run again once with the allocator's blocks
+    given back, then with less and less retained -- context tower, kept layers, the reader's selective layers -- and gives up only when
+    the reference's full recompute does not fit either."""
+    from emdr2_amd.training import RetentionGuard
+
+    class Model:
+        def set_recompute_keep_last(self, n): self.keep = n
+        def set_selective_retention(self, r, c=0, q=0): self.sel = (r, c, q)
+
+    class Opt:
+        zeroed = 0
+        def zero_grad(self): self.zeroed += 1
+        def abort_step(self): pass
+    m, o = Model(), Opt()
+    g = RetentionGuard(m, o, keep=1, reader=4, context=3, query=2)
+    assert m.keep == 1 and m.sel == (4, 3, 2)
+    fails = [9]
+
+    def step():
+        if fails[0] > 0:
+            fails[0] -= 1
+            raise torch.cuda.OutOfMemoryError("injected")
+        return "ok"
+    fails[0] = 1
+    assert g.run(step) == "ok" and g.reruns == 1 and g.plan["thinned"] == 0 and m.sel == (4, 3, 2)      # first failure: same plan again
+    fails[0] = 5
+    assert g.run(step) == "ok"
+    assert g.plan["thinned"] == 4 and m.keep == 0 and m.sel == (2, 0, 0)          # context 3 -> 1 -> 0 (query with it), keep 1 -> 0, reader 4 -> 2
+    fails[0] = 99
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        g.run(step)
+    assert m.sel == (0, 0, 0)
