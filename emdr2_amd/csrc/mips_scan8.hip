@@ -304,30 +304,37 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
             // query column (1.6 survivors per item in the last segment; every slow path holds up the seven other waves at the next barrier)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                float m = acc[mi][ni][0];
+                // the block's max as four quarter maxes (same 15 v_max): a block with a survivor then looks only into the quarters that hold one
+                float mq[4];
 #pragma unroll
-                for (int r = 1; r < 16; ++r) m = fmaxf(m, acc[mi][ni][r]);
+                for (int g = 0; g < 4; ++g) mq[g] = fmaxf(fmaxf(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1]), fmaxf(acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]));
+                const float m = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
                 if (__builtin_amdgcn_ballot_w64(m >= tau) == 0) continue;          // the common case
                 // a block with survivors.  Slots come out of this wave's OWN queue region: the reservation is a scalar add (r03: a ballot, an LDS
                 // atomic by lane 0 and a readfirstlane round trip per register that held a survivor -- most of the filter's cost while the
                 // threshold is still loose); registers without a survivor cost a compare and a scalar branch.
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float v = acc[mi][ni][r];
-                    const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
-                    const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
-                    if (mask == 0) continue;
-                    if ((mask >> elane) & 1ull) {
-                        const unsigned mine = wq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                        if (mine < S8_WCAP) {                                      // (two writes: no aligned register quad to assemble)
-                            ((uint2 *)qbuf)[2 * (wave * S8_WCAP + mine)] = make_uint2(__float_as_uint(v), (unsigned)row);
-                            ((unsigned *)qbuf)[4 * (wave * S8_WCAP + mine) + 2] = q;
-                        } else {                                                   // queue region full: straight to the sub-list
-                            s8_append(p, xcc, q, __float_as_uint(v), (unsigned)row);
-                            stored = true;
+                for (int g = 0; g < 4; ++g) {
+                    if (__builtin_amdgcn_ballot_w64(mq[g] >= tau) == 0) continue;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int r = 4 * g + e;
+                        const float v = acc[mi][ni][r];
+                        const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
+                        const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
+                        if (mask == 0) continue;
+                        if ((mask >> elane) & 1ull) {
+                            const unsigned mine = wq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                            if (mine < S8_WCAP) {                                  // (two writes: no aligned register quad to assemble)
+                                ((uint2 *)qbuf)[2 * (wave * S8_WCAP + mine)] = make_uint2(__float_as_uint(v), (unsigned)row);
+                                ((unsigned *)qbuf)[4 * (wave * S8_WCAP + mine) + 2] = q;
+                            } else {                                               // queue region full: straight to the sub-list
+                                s8_append(p, xcc, q, __float_as_uint(v), (unsigned)row);
+                                stored = true;
+                            }
                         }
+                        wq += (unsigned)__popcll(mask);
                     }
-                    wq += (unsigned)__popcll(mask);
                 }
             }
         }
