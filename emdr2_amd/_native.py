@@ -55,6 +55,7 @@ SIGNATURES["emdr2_transpose_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _
 SIGNATURES.update({
     "emdr2_layernorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "emdr2_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_layernorm_bwd_mask": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _f32, _u32, _vp]),
     "emdr2_softmax_mask_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f32, _u32, _vp]),
     "emdr2_softmax_mask_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _u32, _vp, _vp]),
     "emdr2_softmax_mask_t": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _f32, _u32, _vp]),

@@ -202,9 +202,13 @@ __global__ void __launch_bounds__(256) layernorm_bwd_kernel(const uint16_t *dy, 
 
 // H == 768 backward: half a wave per row with dy and x in registers (one HBM read each), persistent waves accumulate the dgamma / dbeta
 // partials of their 24 columns per lane in registers across all their rows; one LDS reduction and one atomicAdd per column per workgroup.
+// DMASK: also write dx o keep(seed, row, col) / (1 - p) -- the bias-dropout-add below this LayerNorm wants exactly that tensor as the operand of
+// its two backward GEMMs (they read operands by LDS-DMA, so the mask cannot ride in their loads), and r03 made it with a kernel of its own
+// (read dx, write the masked copy: 21 ms of the step).  Same bits as that kernel: the mask is applied to the bf16-ROUNDED dx.
+template <bool DMASK>
 __global__ void __launch_bounds__(256) layernorm_bwd768_kernel(const uint16_t *dy, const uint16_t *x, const float *gamma, const float *mean,
                                                                const float *rstd, const uint16_t *dres, uint16_t *dx, float *dgamma, float *dbeta,
-                                                               long long rows)
+                                                               long long rows, uint16_t *dmask, float drop_p, uint32_t seed)
 {
     __shared__ float red[2][4][768];
     const int lane = threadIdx.x & 63, l31 = lane & 31, half = lane >> 5, wave = threadIdx.x >> 6;
@@ -248,17 +252,26 @@ __global__ void __launch_bounds__(256) layernorm_bwd768_kernel(const uint16_t *d
         for (int o = 16; o >= 1; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         const float m1 = s1 * (1.0f / 768.0f), m2 = s2 * (1.0f / 768.0f);
         uint16_t *xo = dx + row * 768;
+        const float ik = DMASK ? emdr2_keep_scale(drop_p) : 1.f;
+        const uint32_t thr = DMASK ? emdr2_drop_thr(drop_p) : 0u, rh = DMASK ? emdr2_row_hash(seed, (unsigned long long)row) : 0u;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             const uint32_t rw[4] = {rv[i].x, rv[i].y, rv[i].z, rv[i].w};
-            uint32_t o[4];
+            uint32_t o[4], om[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 float a = rs * (g[i][2 * j] - m1 - xh[i][2 * j] * m2), b = rs * (g[i][2 * j + 1] - m1 - xh[i][2 * j + 1] * m2);
                 if (dres) { a += bf2f((uint16_t)(rw[j] & 0xffff)); b += bf2f((uint16_t)(rw[j] >> 16)); }
-                o[j] = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
+                const uint16_t ha = f2bf(a), hb = f2bf(b);
+                o[j] = (uint32_t)ha | ((uint32_t)hb << 16);
+                if (DMASK) {
+                    const uint32_t bits = emdr2_pair_bits(rh, (uint32_t)((i * 32 + l31) * 8 + 2 * j));
+                    const float lo = (bits & 0xffffu) >= thr ? bf2f(ha) * ik : 0.f, hi = (bits >> 16) >= thr ? bf2f(hb) * ik : 0.f;
+                    om[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+                }
             }
             st_stream(xo + (i * 32 + l31) * 8, make_uint4(o[0], o[1], o[2], o[3]));
+            if (DMASK) st_stream(dmask + row * 768 + (i * 32 + l31) * 8, make_uint4(om[0], om[1], om[2], om[3]));
         }
     }
     // both half-waves own the same columns: fold, then reduce the 4 waves through LDS
@@ -799,14 +812,30 @@ extern "C" int emdr2_layernorm_bwd(const void *dy, const void *x, const float *g
     if (H == 768 && al) {
         long long blocks = (rows + 7) / 8;
         if (blocks > 2048) blocks = 2048;                               // persistent: each wave walks ~100 row pairs at the reader's shape
-        hipLaunchKernelGGL(layernorm_bwd768_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy,
-                           (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta, (long long)rows);
+        hipLaunchKernelGGL(layernorm_bwd768_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy,
+                           (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta, (long long)rows,
+                           (uint16_t *)nullptr, 0.f, 0u);
         return LAUNCH_OK();
     }
     const int rpb = LN_ROWS;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(256), 0, (hipStream_t)stream,
                        (const uint16_t *)dy, (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta,
                        (long long)rows, H, rpb);
+    return LAUNCH_OK();
+}
+
+// LayerNorm backward that ALSO writes dmask = dropout_mask(seed) o dx / (1 - p): the operand the bias-dropout-add under this LayerNorm needs for
+// its backward GEMMs (emdr2_dropout would make it from dx in a launch of its own).  H == 768 only (-4 otherwise: the caller keeps the two launches).
+extern "C" int emdr2_layernorm_bwd_mask(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres, void *dx,
+                                        float *dgamma, float *dbeta, int64_t rows, int H, void *dmask, float drop_p, uint32_t seed, void *stream)
+{
+    if (!dy || !x || !gamma || !mean || !rstd || !dx || !dgamma || !dbeta || !dmask || rows < 1 || drop_p <= 0.f || drop_p >= 1.f) return -1;
+    if (H != 768 || (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx | (uintptr_t)dres | (uintptr_t)gamma | (uintptr_t)dmask) & 15)) return -4;
+    long long blocks = (rows + 7) / 8;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(layernorm_bwd768_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint16_t *)dy,
+                       (const uint16_t *)x, gamma, mean, rstd, (const uint16_t *)dres, (uint16_t *)dx, dgamma, dbeta, (long long)rows,
+                       (uint16_t *)dmask, drop_p, seed);
     return LAUNCH_OK();
 }
 

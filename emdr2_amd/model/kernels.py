@@ -251,6 +251,51 @@ class _FanInTable(dict):
 FANIN = _FanInTable()
 
 
+class _PreMask(object):
+    """The backward of a bias-dropout-add (y = x + dropout(z)) needs dy o mask as the operand of two GEMMs.  `dy` is produced by the backward of
+    the LayerNorm that consumed y, so that launch can write the masked copy on its way (csrc/elementwise.hip: layernorm_bwd768_kernel<true>)
+    instead of a dropout launch re-reading dy.  Forward: the bias-dropout-add registers (p, seed) under its output's address (`want`);
+    backward: the LayerNorm backward whose INPUT has that address leaves (address of dx, p, seed) -> masked tensor in the one `slot`; the
+    bias-dropout-add's backward takes it if every part of the key matches and falls back to the dropout kernel otherwise.  One slot: the
+    consumer is the next node autograd runs, anything else overwrites or clears it, so at most one extra [tokens, h] tensor is alive."""
+
+    def __init__(self):
+        self.want, self.slot, self.enabled, self.fused, self.unfused = {}, None, True, 0, 0
+
+    def register(self, y, drop_p, seed):
+        if self.enabled and drop_p > 0.0:
+            self.want[y.data_ptr()] = (float(drop_p), int(seed), y.numel())
+
+    def request_for(self, x2):
+        req = self.want.pop(x2.data_ptr(), None)
+        return req if (req is not None and req[2] == x2.numel()) else None
+
+    def take(self, dy2, drop_p, seed):
+        slot, self.slot = self.slot, None
+        if slot is not None and slot[0] == (dy2.data_ptr(), float(drop_p), int(seed)) and slot[1].shape == dy2.shape:
+            self.fused += 1
+            return slot[1]
+        self.unfused += 1
+        return None
+
+    def clear(self):
+        self.want.clear()
+        self.slot = None
+
+
+PREMASK = _PreMask()
+
+
+def _dropout_mask_of(dy2, N, drop_p, seed):
+    """dy o keep(seed) / (1 - p) for the backward GEMMs of a bias-dropout-add: from the LayerNorm backward that made dy, else by its own kernel."""
+    pre = PREMASK.take(dy2, drop_p, seed)
+    if pre is not None:
+        return pre
+    dmask = torch.empty_like(dy2)
+    _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), N, drop_p, seed, _sp()), "dropout")
+    return dmask
+
+
 class FanInFn(torch.autograd.Function):
     """y = x for a tensor that feeds MANY linear layers (the FiD reader's encoder output: the K/V projection of every decoder layer reads all
     K * S encoder tokens).  Autograd would materialise each consumer's [tokens, h] input gradient and sum them pairwise (11 additions of
@@ -416,7 +461,7 @@ class LinearFn(torch.autograd.Function):
     p = 0: mpu/layers.py:255,353, transformer.py:94-108,397-407).  W, b are fp32 masters; GEMMs run on bf16 copies."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gelu, residual, row_perm=None, drop_p=0.0, seed=0):
+    def forward(ctx, x, weight, bias, gelu, residual, row_perm=None, drop_p=0.0, seed=0, grad_on=True):
         _check_bf16(x, residual)
         shp = x.shape
         x2 = x.reshape(-1, shp[-1])
@@ -432,6 +477,8 @@ class LinearFn(torch.autograd.Function):
         if bias is not None:
             bb = bias.detach() if row_perm is None else WEIGHTS.get(bias, "perm", lambda: bias.detach()[row_perm].contiguous())
         gemm_nt(x2, K, wb, K, y, N, M, N, K, bias=bb, gelu=gelu, pre_act=pre, residual=res2, drop_p=drop_p, seed=seed)
+        if grad_on and ATTN_STASH.mode != 'store':           # a backward will really run from THIS forward (cf. MLPFn.forward)
+            PREMASK.register(y, drop_p, seed)
         ctx.save_for_backward(x2, pre)
         ctx.drop_p, ctx.seed = drop_p, seed
         ctx.weight, ctx.bias, ctx.gelu, ctx.has_res, ctx.shp, ctx.row_perm = weight, bias, gelu, residual is not None, shp, row_perm
@@ -448,9 +495,7 @@ class LinearFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dres = dy if ctx.has_res else None
         if ctx.drop_p > 0.0:                                                              # the epilogue's dropout mask, regenerated
-            dmask = torch.empty_like(dy2)
-            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), N, ctx.drop_p, ctx.seed, _sp()), "dropout")
-            dy2 = dmask
+            dy2 = _dropout_mask_of(dy2, N, ctx.drop_p, ctx.seed)
         if ctx.gelu:
             dpre = torch.empty_like(dy2)
             _native.check(_lib().emdr2_gelu_bwd(pre.data_ptr(), dy2.data_ptr(), dpre.data_ptr(), dy2.numel(), _sp()), "gelu_bwd")
@@ -470,11 +515,11 @@ class LinearFn(torch.autograd.Function):
             if M % 32:
                 raise ValueError("token count must be a multiple of 32 for the weight-gradient GEMM")
             _linear_param_grads(dy2, x2, weight, bias, ctx.row_perm)                      # [N, K] fp32 = dy^T x (+ bias gradient), no transposes
-        return dx, None, None, None, dres, None, None, None
+        return dx, None, None, None, dres, None, None, None, None
 
 
 def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None, drop_p=0.0, seed=0):
-    return LinearFn.apply(x, weight, bias, gelu, residual, row_perm, drop_p, seed)
+    return LinearFn.apply(x, weight, bias, gelu, residual, row_perm, drop_p, seed, torch.is_grad_enabled())
 
 
 class MLPFn(torch.autograd.Function):
@@ -503,6 +548,8 @@ class MLPFn(torch.autograd.Function):
         gemm_nt(x2, H, w_bf16(w1), H, inter, F, M, F, H, bias=b1.detach(), gelu=2 if need_pre else 1, pre_act=pre)
         y = torch.empty((M, H), dtype=BF16, device=x.device)
         gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=residual.reshape(M, H), drop_p=drop_p, seed=seed)
+        if need_pre:
+            PREMASK.register(y, drop_p, seed)
         # (a placeholder keeps the NUMBER of saved tensors equal between a checkpointed layer's first run and its re-run, which is how
         # torch.utils.checkpoint pairs them up)
         ctx.save_for_backward(x2, pre if pre is not None else x2.new_empty(0), inter)
@@ -524,9 +571,7 @@ class MLPFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dres = dy
         if ctx.drop_p > 0.0:
-            dmask = torch.empty_like(dy2)
-            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), H, ctx.drop_p, ctx.seed, _sp()), "dropout")
-            dy2 = dmask
+            dy2 = _dropout_mask_of(dy2, H, ctx.drop_p, ctx.seed)
         # d(pre) = (dy W2) * gelu'(pre): the multiply rides in the GEMM epilogue (`pre` holds the derivative, see forward)
         dpre = torch.empty((M, F), dtype=BF16, device=dy.device)
         gemm_nt(dy2, H, w_bf16_t(w2), H, dpre, F, M, F, H, residual=pre, residual_mode=2)
@@ -585,8 +630,19 @@ def _ln_backward(dy2, x2, gamma, beta, mean, rstd, dres):
     rows, H = x2.shape
     dx = torch.empty_like(x2)
     (dg, dg_direct), (db, db_direct) = _grad_buffer(gamma), _grad_buffer(beta)            # the kernel adds its column sums atomically
-    _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
-                                             dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
+    req = PREMASK.request_for(x2)          # x2 is the output of a bias-dropout-add whose backward runs next and wants dx o mask
+    rc = -4
+    if req is not None:
+        dmask = torch.empty_like(x2)
+        rc = _lib().emdr2_layernorm_bwd_mask(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(),
+                                             dg.data_ptr(), db.data_ptr(), rows, H, dmask.data_ptr(), req[0], req[1], _sp())
+        if rc == 0:
+            PREMASK.slot = ((dx.data_ptr(), req[0], req[1]), dmask)
+        elif rc != -4:
+            _native.check(rc, "layernorm_bwd_mask")
+    if rc == -4:
+        _native.check(_lib().emdr2_layernorm_bwd(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres),
+                                                 dx.data_ptr(), dg.data_ptr(), db.data_ptr(), rows, H, _sp()), "layernorm_bwd")
     _deliver_grad(gamma, dg, dg_direct)
     _deliver_grad(beta, db, db_direct)
     return dx
@@ -667,7 +723,7 @@ class LNMLPFn(torch.autograd.Function):
     flops instead of all of them (per-layer recompute) or none (keeping 32 GB per layer at the benchmark shape)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed):
+    def forward(ctx, x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed, grad_on=True):
         _check_bf16(x)
         H = x.shape[-1]
         x2 = x.reshape(-1, H)
@@ -680,6 +736,8 @@ class LNMLPFn(torch.autograd.Function):
         del ln
         y = torch.empty((M, H), dtype=BF16, device=x.device)
         gemm_nt(inter, F, w_bf16(w2), F, y, H, M, H, F, bias=b2.detach(), residual=x2, drop_p=drop_p, seed=seed)
+        if grad_on:
+            PREMASK.register(y, drop_p, seed)
         ctx.save_for_backward(x2, mean, rstd)
         ctx.params, ctx.eps, ctx.shp, ctx.drop_p, ctx.seed = (gamma, beta, w1, b1, w2, b2), eps, x.shape, drop_p, seed
         return y.reshape(x.shape)
@@ -697,9 +755,7 @@ class LNMLPFn(torch.autograd.Function):
             dy2 = dy2.contiguous()
         dres = dy2                                                                        # the residual branch: y = x + ...
         if ctx.drop_p > 0.0:
-            dmask = torch.empty_like(dy2)
-            _native.check(_lib().emdr2_dropout(dy2.data_ptr(), dmask.data_ptr(), dy2.numel(), H, ctx.drop_p, ctx.seed, _sp()), "dropout")
-            dy2 = dmask
+            dy2 = _dropout_mask_of(dy2, H, ctx.drop_p, ctx.seed)
         # rebuild LayerNorm output, FFN pre-activation and GELU output
         RECOMPUTE.active += 1
         try:
@@ -719,11 +775,11 @@ class LNMLPFn(torch.autograd.Function):
         dln = matmul_nt(dpre, w_bf16_t(w1))
         del dpre
         dx = _ln_backward(dln, x2, gamma, beta, mean, rstd, dres)
-        return dx.reshape(ctx.shp), None, None, None, None, None, None, None, None, None
+        return dx.reshape(ctx.shp), None, None, None, None, None, None, None, None, None, None
 
 
 def ln_mlp(x, gamma, beta, eps, w1, b1, w2, b2, drop_p=0.0, seed=0):
-    return LNMLPFn.apply(x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed)
+    return LNMLPFn.apply(x, gamma, beta, eps, w1, b1, w2, b2, drop_p, seed, torch.is_grad_enabled())
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

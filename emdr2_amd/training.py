@@ -209,6 +209,7 @@ class FlatAdam(object):
         from emdr2_amd.model import kernels
         kernels.ATTN_STASH.store.clear()      # entries of a forward whose backward never ran must not outlive the step
         kernels.FANIN.clear()
+        kernels.PREMASK.clear()
 
     def begin_step(self):
         self._stale = False

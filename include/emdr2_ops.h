@@ -60,6 +60,10 @@ int emdr2_layernorm_fwd(const void *x, const float *gamma, const float *beta, vo
                         float eps, void *stream);
 int emdr2_layernorm_bwd(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres, void *dx,
                         float *dgamma, float *dbeta, int64_t rows, int H, void *stream);
+/* The same, ALSO writing dmask = dx * keep(seed, row, col) / (1 - drop_p) (bf16 [rows, H], the bits of emdr2_dropout(dx, ...)): the operand of the
+ * backward GEMMs of the bias-dropout-add (transformer.py:397-413) that produced x.  H == 768 only; -4 otherwise. */
+int emdr2_layernorm_bwd_mask(const void *dy, const void *x, const float *gamma, const float *mean, const float *rstd, const void *dres, void *dx,
+                             float *dgamma, float *dbeta, int64_t rows, int H, void *dmask, float drop_p, uint32_t seed, void *stream);
 
 /* Scale-mask-softmax, the path the shipped scripts run (fused_softmax.py:113-125): masked scores are REPLACED by -10000
  * (bert/t5_attention_mask_func), masks derived on the fly from token ids (pad id 0; mask_creation_utils.py:17-42),
