@@ -87,6 +87,7 @@ def setup(args, rank, world, index=None, topk=50):
     B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
     Kmod.PACKING.enabled = not getattr(args, "no_packing", False)
     Kmod.PACKING.sticky, Kmod.PACKING.capacity = True, {}    # constant activation sizes from step to step (allocator reuse)
+    Kmod.PREMASK.enabled = os.environ.get("EMDR2_PREMASK", "1") != "0"          # A/B switch: dropout masks of the backward from the LayerNorm backward (default) or their own launches
     if index is None:
         index = build_index(args.rows, rank, world)
     arena = EvidenceArena.synthetic(args.rows)
