@@ -119,6 +119,25 @@ def test_two_rank_data_parallel_training_over_rccl(tmp_path):
         assert torch.equal(a, b)
 
 
+def test_bench_under_the_drivers_launcher_is_not_launched_twice():
+    """The other form of the multi-GPU command (`python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N`, the task statement's):
+    inside a launcher's rank WORLD_SIZE is set and `dist_util.self_launch` must do nothing."""
+    import json
+    import subprocess
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           "bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "1000000", "--no-e2e", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["config"]["rows_per_rank"] == [500000, 500000] and r["config"]["unproven_queries"] == 0
+
+
 def _plain_bench(extra_env=None, extra_args=()):
     """`python bench.py --gpus 2 ...` exactly as the driver types it -- NO launcher around it (bench.py starts its own ranks through
     dist_util.self_launch) -- as 2 gloo ranks sharing cuda:0 (EMDR2_SINGLE_DEVICE) at a reduced size."""
