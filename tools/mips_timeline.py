@@ -45,6 +45,6 @@ t0, prev_end = last[0][0], last[0][0]
 print("one search: %s rows, %s queries, top-%s" % (rows, nq, k))
 print("%10s %10s %8s  %s" % ("start us", "dur us", "gap us", "kernel"))
 for s, e, name in last:
-    print("%10.1f %10.1f %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name.split("(")[0][-60:]))
+    print("%10.1f %10.1f %8.1f  %s" % ((s - t0) / 1e3, (e - s) / 1e3, (s - prev_end) / 1e3, name.replace("(anonymous namespace)::", "").split("(")[0][-60:]))
     prev_end = e
 print("total %.1f us from the first launch's start to the last one's end; kernels busy %.1f us" % ((last[-1][1] - t0) / 1e3, sum(e - s for s, e, _ in last) / 1e3))
