@@ -1,5 +1,6 @@
+# A/B of two library builds on the four NT shapes of the step: rate, error against fp32 on the first 512 rows, run-to-run repeatability.  usage: python tools/gemm_ab.py [--lib path/to/libemdr2_hip.so]
 import os, sys, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from emdr2_amd import _native
 if "--lib" in sys.argv:
     i = sys.argv.index("--lib"); _native.LIB_PATH = os.path.abspath(sys.argv[i + 1])
