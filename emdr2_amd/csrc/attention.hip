@@ -137,7 +137,7 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     // A padded query has every score replaced by -10000: per-lane (scale, offset) = (0, -10000 log2 e) does that without a select.
     const float sc_q = qpad ? 0.f : p.scale * L2E, c_q = qpad ? MASKED2 : 0.f;
     const bool any_qpad = __builtin_amdgcn_ballot_w64(qpad) != 0ull;
-    const bool all_qpad = __builtin_amdgcn_ballot_w64(qpad) == ~0ull;      // a wave entirely inside the padding of its sequence
+    const float raw_masked = MASKED2 / (p.scale * L2E);                       // the raw score that a real query's affine map sends to the mask value
     float mrun = -3.0e38f, lrun = 0.f;
     const float ik = DROP ? emdr2_keep_scale(p.drop_p) : 1.f;
     const uint32_t thr = emdr2_drop_thr(p.drop_p);
@@ -177,9 +177,6 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
             if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
                 __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
                 continue;
-            // The rest of the step is instantiated three times (padded wave / masks needed / mask-free) instead of branching inside one body:
-            // a join after the score section made the compiler copy the 16 score registers (and, for the padded path, the 32 of O) at
-            // every step to reconcile the register assignments of the paths.
             auto dropout_and_pv = [&](floatx16 &sacc) {
                 if (DROP) {                                                       // attention dropout after the normaliser (l is un-dropped)
                     const uint32_t prod0 = ((uint32_t)(kb0 + 4 * hi) >> 1) * EMDR2_PAIR_MUL;
@@ -210,17 +207,6 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                     oacc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vt1, pf, oacc[1], 0, 0, 0);
                 }
             };
-            if (all_qpad) {
-                // Every score of this wave is the mask value -10000: the softmax is uniform over ALL keys.  Same numbers as the general
-                // path below produces for padded queries (scale 0, offset -10000 -> exp2(0) = 1 per key), without the QK^T MFMAs and exps.
-                floatx16 sacc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = (kb0 + (r & 3) + 8 * (r >> 2) + 4 * hi < sk) ? 1.f : 0.f;   // (packed: keys past sk do not exist)
-                mrun = MASKED2;
-                lrun += (float)min(32, sk - kb0);
-                dropout_and_pv(sacc);
-                continue;
-            }
             // ---- S^T = K Q^T : 32 keys x 4 k-steps -------------------------------------------------------------------------------
             const floatx16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // inline-constant C operand: no v_mov per register
             // two fragments at a time: all four at once cost eight more live registers than the 168 of three waves per SIMD allow
@@ -236,58 +222,55 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
                 sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[1], qf[2 * tp + 1], sacc, 0, 0, 0);
             }
             // ---- mask, online softmax (this lane: one query, 16 of the 32 keys; its half-wave partner holds the other 16) --------
-            const bool need_mask = km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0);   // wave-uniform
-            auto softmax_step = [&](auto masks) {
-                constexpr bool MASKS = decltype(masks)::value;
-                float bmax, bsum = 0.f;
-                if (!MASKS) {
-                    float mx = sacc[0];
+            // ONE path with one-armed, wave-uniform `if`s around the rare parts, each of which touches the score registers only (or, the
+            // rescale, O in place).  r01-r03 ran two instantiations of the whole section, `if (need_mask) A else B`, each with the
+            // rescale and the PV product inside: LLVM structurizes a region with more than one conditional child even when every branch
+            // is wave-uniform, a structurized if / else runs its arms one after the other as far as register allocation is concerned, O
+            // had to survive the arm that "does not run" -- and every 32-key step copied the 32 registers of O to a second set and back
+            // (32 v_mov_b64 of ~210 VALU instructions on the mask-free path).  Masks are applied to the RAW scores: a masked key gets the
+            // raw value that the affine map below sends to -10000 log2(e) (a real query; a padded query has scale 0 and lands there
+            // whatever the raw value), keys past the end of a packed sequence hold a copy of the last real key's score (the DMA re-reads
+            // that row), so they cannot disturb the max, and are zeroed after the exponential: probability 0 even for a padded query,
+            // so the forward agrees with the backward, which never stores such a key's dK / dV.
+            if (km != 0xffffffffu || (CAUSAL && kb0 + 31 > q0)) {                  // wave-uniform
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
-                    bmax = fmaf(mx, sc_q, c_q);                                  // sc_q >= 0: max commutes with the affine map
-                } else {
-                    bmax = -3.0e38f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;          // key inside the sub-block
-                        const bool masked = !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
-                        float s2 = masked ? MASKED2 : fmaf(sacc[r], sc_q, c_q);
-                        // a key past the end of a packed sequence does not exist: probability 0 even for a padded query (whose softmax is
-                        // uniform over the sk keys that do), so the forward agrees with the backward, which never stores such a key's dK / dV
-                        s2 = kb0 + kl < sk ? s2 : -3.0e38f;
-                        sacc[r] = s2;
-                        bmax = fmaxf(bmax, s2);
-                    }
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = (r & 3) + 8 * (r >> 2) + 4 * hi;              // key inside the sub-block
+                    const bool masked = !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
+                    sacc[r] = masked ? raw_masked : sacc[r];
                 }
-                bmax = half_max(bmax);
-                // LAZY running max: the reference point of the exponentials only moves when some query's block max exceeds it by more than
-                // 2^8 -- with 32 queries per wave the exact max moves in almost every step (and each move costs a rescale of the 32 O
-                // registers: 3 of 10 VALU slots per score), a jump of 8 happens in the first step and then practically never.  Until then
-                // exp2(s - m) <= 256: nothing for fp32 sums or bf16 probabilities (same relative precision), and O / l is unchanged
-                // mathematically; (m, l) stay consistent for the backward, which only ever uses m + log2 l.
-                if (__builtin_amdgcn_ballot_w64(bmax > mrun + 8.f) != 0ull) {
-                    const float mnew = fmaxf(mrun, bmax);
-                    const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
-                    lrun *= alpha;
+            }
+            float mx = sacc[0];
 #pragma unroll
-                    for (int jj = 0; jj < 2; ++jj)
+            for (int r = 1; r < 16; ++r) mx = fmaxf(mx, sacc[r]);
+            const float bmax = half_max(fmaf(mx, sc_q, c_q));                    // sc_q >= 0: max commutes with the affine map
+            // LAZY running max: the reference point of the exponentials only moves when some query's block max exceeds it by more than
+            // 2^8 -- with 32 queries per wave the exact max moves in almost every step (and each move costs a rescale of the 32 O
+            // registers: 3 of 10 VALU slots per score), a jump of 8 happens in the first step and then practically never.  Until then
+            // exp2(s - m) <= 256: nothing for fp32 sums or bf16 probabilities (same relative precision), and O / l is unchanged
+            // mathematically; (m, l) stay consistent for the backward, which only ever uses m + log2 l.
+            if (__builtin_amdgcn_ballot_w64(bmax > mrun + 8.f) != 0ull) {
+                const float mnew = fmaxf(mrun, bmax);
+                const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
+                lrun *= alpha;
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) oacc[jj][r] *= alpha;
-                    mrun = mnew;
-                }
-                if (!MASKS) {
-                    const float off = c_q - mrun;
+                for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc_q, off)); sacc[r] = e; bsum += e; }
-                } else {
+                    for (int r = 0; r < 16; ++r) oacc[jj][r] *= alpha;
+                mrun = mnew;
+            }
+            const float off = c_q - mrun;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) { const float e = __builtin_amdgcn_exp2f(sacc[r] - mrun); sacc[r] = e; bsum += e; }
-                }
-                lrun += half_sum(bsum);
-                dropout_and_pv(sacc);
-            };
-            if (need_mask) softmax_step(std::true_type{});
-            else softmax_step(std::false_type{});
+            for (int r = 0; r < 16; ++r) sacc[r] = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc_q, off));
+            if (kb0 + 32 > sk) {                                                    // (packed: the ragged end of the sequence)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sacc[r] = kb0 + (r & 3) + 8 * (r >> 2) + 4 * hi < sk ? sacc[r] : 0.f;
+            }
+            float bsum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) bsum += sacc[r];
+            lrun += half_sum(bsum);
+            dropout_and_pv(sacc);
         }
     }
 
