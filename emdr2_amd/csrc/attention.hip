@@ -59,19 +59,20 @@ __device__ __forceinline__ float half_sum(float x)
 #define QB (NW * QW)  // queries per workgroup
 
 // DROP / CAUSAL are compile-time: the instances without them carry neither the hash nor the history-mask arithmetic.  The kernel is VALU-bound
-// (rocprofv3: ~35 VALU instructions per MFMA, VALU busy 4.6x the matrix pipe), so what matters is keeping the VALU issuing: two workgroups per
-// CU (4 waves per SIMD) need <= 128 VGPRs, which is why a 64-key block is consumed as two 32-key online-softmax steps (16 score registers live
-// instead of 32) and a workgroup is FOUR waves (128 queries): three workgroups per CU = 3 waves per SIMD at <= 168 VGPRs, each with its own
-// barrier, so one workgroup's softmax arithmetic runs under another's MFMAs and DMA waits.
+// (rocprofv3: ~35 VALU instructions per MFMA, VALU busy 4.6x the matrix pipe), so what matters is keeping the VALU issuing: a 64-key block is
+// consumed as two 32-key online-softmax steps (16 score registers live instead of 32) and a workgroup is FOUR waves (128 queries), each
+// workgroup with its own barrier, so that one workgroup's softmax arithmetic runs under another's MFMAs and DMA waits.  r04: FOUR workgroups per
+// CU (4 waves per SIMD: <= 128 VGPRs -- 120 - 128 since the softmax section is one path, see there -- and 32 KiB of LDS each).
 template <bool DROP, bool CAUSAL>
-__global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
+__global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_fwd_kernel(AttnParams p)   // (dropout + causal: 134 VGPRs)
 {
-    // LDS (dynamic): 3 stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h), then the
-    // key-padding bits, one 64-bit word per 64-key block.  Three stages = TWO blocks of DMA in flight while one is consumed: a packed
-    // sequence of ~140 tokens is 3 blocks in all, and with a one-block look-ahead every block paid a full memory latency (the softmax of a
-    // block takes ~0.5 us, the fetch of the next one 1 - 2 us).  48 KiB + the mask words keeps three workgroups on a CU.
+    // LDS (dynamic): NST stages x (K tile + V tile, each [64 keys][64 d] 8 KiB, granules swizzled as in attention_common.h), then the
+    // key-padding bits, one 64-bit word per 64-key block.  r03 ran THREE stages (two blocks of DMA in flight while one is consumed) at three
+    // workgroups per CU; with the registers for a fourth, two stages and four workgroups measure better on every shape (context tower 1.07 ->
+    // 0.99 ms, reader pairs 4.02 -> 3.92, dense 417 -> 428 TFLOP/s): the fetch of the next block is covered by three other workgroups now.
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    unsigned long long *kmask_s = (unsigned long long *)(smem + 3 * 16384);
+    constexpr int NST = 2;
+    unsigned long long *kmask_s = (unsigned long long *)(smem + NST * 16384);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
@@ -107,10 +108,9 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + NW * i) * 1024), 16, 0, 0);
         }
     };
-    // the first two K / V blocks go out before anything else touches global memory: short (packed) sequences have only 2 - 4 blocks per
+    // the first K / V block goes out before anything else touches global memory: short (packed) sequences have only 2 - 4 blocks per
     // workgroup, and a prologue that first waits for its Q rows and key ids and only then starts the DMA pays the memory latency twice
     issue(0, 0);
-    if (nblk > 1) issue(1, 1);
 
     // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
     const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
@@ -147,17 +147,14 @@ __global__ void __launch_bounds__(NW * 64, 3) attention_fwd_kernel(AttnParams p)
     // itself it would put the wait for the Q rows at their first use inside the loop, as vmcnt(0) -- and drain the look-ahead DMA with it
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
     int stage = 0;
-    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
-        // this block's tiles have landed once at most the NEXT block's pieces (2 x 8 / NW DMA instructions of this wave, issued later and
-        // retired in order) are still in flight; everything older -- Q rows, key ids -- has long returned
-        if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / NW)) : "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        // raw barrier: __syncthreads() carries a workgroup fence, i.e. s_waitcnt vmcnt(0) -- it would wait for the look-ahead DMA as well.
-        // What must be ordered here is LDS only: the mask words of the prologue and (through each wave's own counted wait above) the tiles.
+    for (int blk = 0; blk < nblk; ++blk, stage ^= 1) {
+        // this block's pieces are the newest DMA of this wave (the next block's go out after the barrier)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // raw barrier: what must be ordered here is LDS only -- the mask words of the prologue and (through each wave's own wait above) the tiles
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                                             // every wave's pieces have landed; everyone is done with the block before
         __builtin_amdgcn_sched_barrier(0);
-        if (blk + 2 < nblk) issue(blk + 2, stage == 0 ? 2 : stage - 1);           // into the stage the previous block has just left
+        if (blk + 1 < nblk) issue(blk + 1, stage ^ 1);                            // into the stage the previous block has just left
         if (!wave_live) continue;
         const unsigned long long kmask = kmask_s[blk];
         const int key0 = blk * KB;
@@ -313,7 +310,7 @@ static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
     dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads, heads));
-    const size_t lds = 3 * 16384 + (size_t)((sk + KB - 1) / KB) * 8;            // <= 56 KiB (sk <= 65536): under the 64 KiB a kernel gets without opting in
+    const size_t lds = 2 * 16384 + (size_t)((sk + KB - 1) / KB) * 8;            // <= 40 KiB (sk <= 65536)
     OpsTimer timer(OPS_ATTN_FWD, 4.0 * heads * pairs * 64, (hipStream_t)stream);
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
