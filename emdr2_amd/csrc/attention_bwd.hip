@@ -209,19 +209,24 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int r = 4 * g + e;
-                    const int kl = 8 * g + 4 * hi + e;
                     const float pr = __builtin_amdgcn_exp2f(fmaf(sacc[r], sc, -pm));
                     float gr = pacc[r];
                     if (DROP) {
                         const uint32_t bits = e < 2 ? b0 : b1;
                         gr = ((e & 1) ? (bits >> 16) : (bits & 0xffffu)) >= thr ? gr : 0.f;
                     }
-                    float ds = pr * (gr - Dk);                            // dS / keep_scale (dQ is scaled once, at the end)
-                    if (need_mask) {
-                        const bool masked = qpad || !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
-                        ds = masked ? 0.f : ds;
-                    }
-                    sacc[r] = ds;
+                    sacc[r] = pr * (gr - Dk);                              // dS / keep_scale (dQ is scaled once, at the end)
+                }
+            }
+            // masks are rare (padding, the causal diagonal): ONE wave-uniform branch around all sixteen selects.  Tested per score
+            // (`if (need_mask)` inside the loops above) the compiler turns the branch into arithmetic and every score pays the bit test, the
+            // compare and the select whether a mask exists or not: 3 of 18 VALU instructions per score.
+            if (need_mask) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kl = 8 * (r >> 2) + 4 * hi + (r & 3);
+                    const bool masked = qpad || !((km >> kl) & 1u) || (CAUSAL && kb0 + kl > qi);
+                    sacc[r] = masked ? 0.f : sacc[r];
                 }
             }
             // dQ^T += K^T dS^T
