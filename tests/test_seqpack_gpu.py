@@ -143,6 +143,42 @@ def test_packed_self_attention_equals_dense(n, S, heads, causal):
     assert float(qkv.grad[~real].abs().max()) == 0.0
 
 
+@pytest.mark.parametrize("causal", [False, True])
+def test_packed_self_attention_at_every_block_boundary(causal):
+    """One packed batch whose sequence lengths sit on, one below and one above every tiling boundary of the attention kernels (32-key
+    softmax steps, 64-key staged blocks, 128-query / 128-key workgroups): the ragged ends are where the one-path forward of round 4 masks
+    raw scores, zeroes keys past the end after the exponential and where the backward kernels switch to their masked arms."""
+    from emdr2_amd.model import kernels as K
+    lens = [1, 2, 31, 32, 33, 63, 64, 65, 95, 96, 97, 127, 128, 129, 160, 191, 192, 193, 255, 256]
+    n, S, heads = len(lens), 256, 2
+    rng = np.random.default_rng(5)
+    ids = np.zeros((n, S), dtype=np.int64)
+    for i, ln in enumerate(lens):
+        ids[i, :ln] = rng.integers(1, 500, ln)
+    ids_t = torch.from_numpy(ids).cuda()
+    real = ids_t != 0
+    g = torch.Generator(device="cuda").manual_seed(9)
+    qkv = torch.randn((n, S, 3, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    out_d = K.attention_core(qkv, None, ids_t, ids_t, causal)
+    w = torch.randn(out_d.shape, generator=g, device="cuda") * real[..., None, None]
+    (out_d.float() * w).sum().backward()
+    grad_d = qkv.grad.clone(); qkv.grad = None
+    seqs = K.PackedSeqs(ids_t)
+    qkv_p = K.pack_rows(qkv.reshape(n, S, -1), seqs).reshape(seqs.rows, 3, heads, 64)
+    out_p = K.attention_core(qkv_p, None, seqs, seqs, causal)
+    back = K.unpack_rows(out_p.reshape(seqs.rows, -1), seqs).reshape(n, S, heads, 64)
+    (back.float() * w).sum().backward()
+    for i, ln in enumerate(lens):                                                 # per sequence: a failure names the length
+        assert _rel(back[i, :ln], out_d[i, :ln]) < 1e-5, (ln, _rel(back[i, :ln], out_d[i, :ln]))
+        assert _rel(qkv.grad[i, :ln], grad_d[i, :ln]) < 2e-3, (ln, _rel(qkv.grad[i, :ln], grad_d[i, :ln]))
+    assert float(qkv.grad[~real].abs().max()) == 0.0
+    # and the dense launch itself against fp32 torch at the same lengths (padded queries and keys inside one grid)
+    from tests.test_ops_gpu import _attention_reference
+    qf = qkv.detach().float()
+    ref = _attention_reference(qf[:, :, 0], qf[:, :, 1], qf[:, :, 2], ids_t, ids_t, causal, None)
+    assert _rel(out_d[real].float(), ref[real]) < 1e-2, _rel(out_d[real].float(), ref[real])
+
+
 @pytest.mark.parametrize("B,Kk,S,L,heads", [(2, 3, 64, 32, 2), (3, 5, 96, 32, 2), (2, 50, 512, 32, 1)])
 def test_cross_attention_over_packed_keys_equals_dense(B, Kk, S, L, heads):
     """FiD: dense decoder queries [B, L] against the K passages of a question concatenated -- dense keys [B, K * S] (pad rows masked) vs the
