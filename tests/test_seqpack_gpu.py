@@ -208,6 +208,50 @@ def test_cross_attention_over_packed_keys_equals_dense(B, Kk, S, L, heads):
     assert _rel(kv.grad[real], gkv[real]) < 2e-3 and float(kv.grad[~real].abs().max()) == 0.0
 
 
+def test_packed_attention_dropout_mask_exact_at_block_boundaries():
+    """Dropout on the packed launch, element by element: the keep bit of (head n, packed row r, key k of r's sequence) is the site hash at
+    (row n * rows + r, column k) -- the same generator as every other dropout site -- so a torch reference with that mask pins forward, dq
+    and dk / dv (mask-free and masked arms, the ragged last steps) at lengths around every tiling boundary."""
+    from emdr2_amd.model import kernels as K
+    from tests.test_ops_gpu import _attention_reference, _dropout_mask
+    lens = [1, 31, 32, 33, 64, 65, 96, 127, 128, 129, 200, 256]
+    n, S, heads, p, seed = len(lens), 256, 2, 0.2, 4711
+    rng = np.random.default_rng(6)
+    ids = np.zeros((n, S), dtype=np.int64)
+    for i, ln in enumerate(lens):
+        ids[i, :ln] = rng.integers(1, 500, ln)
+    ids_t = torch.from_numpy(ids).cuda()
+    seqs = K.PackedSeqs(ids_t)
+    g = torch.Generator(device="cuda").manual_seed(10)
+    qkv = torch.randn((n, S, 3, heads, 64), generator=g, device="cuda").bfloat16()
+    qkv_p = K.pack_rows(qkv.reshape(n, S, -1), seqs).reshape(seqs.rows, 3, heads, 64).detach().requires_grad_(True)
+    out = K.attention_core(qkv_p, None, seqs, seqs, False, drop_p=p, seed=seed)
+    w = torch.randn(out.shape, generator=g, device="cuda")
+    w[seqs.total:] = 0
+    (out.float() * w).sum().backward()
+    mask = _dropout_mask((heads * seqs.rows, S), p, seed).reshape(heads, seqs.rows, S)
+    cu = seqs.cu.cpu().numpy()
+    ref_out, ref_grad = torch.zeros_like(out, dtype=torch.float32), torch.zeros_like(qkv_p, dtype=torch.float32)
+    for i, ln in enumerate(lens):
+        c0 = int(cu[i])
+        x = qkv_p.detach()[c0:c0 + ln].float()[None].requires_grad_(True)             # [1, ln, 3, heads, 64]
+        one = torch.ones((1, ln), dtype=torch.long, device="cuda")
+        ref = _attention_reference(x[:, :, 0], x[:, :, 1], x[:, :, 2], one, one, False, mask[None, :, c0:c0 + ln, :ln])
+        (ref * w[None, c0:c0 + ln]).sum().backward()
+        ref_out[c0:c0 + ln], ref_grad[c0:c0 + ln] = ref[0].detach(), x.grad[0]
+    # per sequence (a failure names the length), against the scale of the whole tensor: the one-token sequence's dq is exactly 0 in the
+    # reference and rounding noise of D = rowsum(dO o O) here
+    so = float(ref_out.abs().max())
+    sg = [float(ref_grad[:, j].abs().max()) for j in range(3)]
+    for i, ln in enumerate(lens):
+        c0 = int(cu[i])
+        e = float((out.detach()[c0:c0 + ln].float() - ref_out[c0:c0 + ln]).abs().max()) / so
+        assert e < 2e-2, (ln, "out", e)
+        for j, name in enumerate(("dq", "dk", "dv")):
+            e = float((qkv_p.grad[c0:c0 + ln, j].float() - ref_grad[c0:c0 + ln, j]).abs().max()) / sg[j]
+            assert e < 3e-2, (ln, name, e)
+
+
 def test_packed_attention_dropout_statistics_and_backward_consistency():
     """With dropout the packed launch draws its own mask (keyed by the packed row), so it cannot equal the dense launch element-wise: check
     the keep rate through the output's expectation and that forward and backward use the SAME mask (gradient of a linear functional)."""
