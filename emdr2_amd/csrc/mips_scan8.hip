@@ -24,6 +24,8 @@
 
 namespace {
 
+typedef float floatx4 __attribute__((ext_vector_type(4)));
+
 #define S8_BUF 65536
 #define S8_SLOT 16384
 #define S8_QCAP 2040              // survivor queue entries (16 B each); the counters sit behind them
@@ -93,13 +95,13 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     // the workgroups of an XCD stride the sequence by an even count (host) and `per` is even: a workgroup keeps ONE query half for all its items,
     // so its thresholds are loaded once (a load in the filter would wait out the whole DMA queue: vmcnt is in order)
     const int hq = P.halves == 2 ? first & 1 : 0;
-    float tauv[2];
+    float tauv[4];                                             // the wave's four 16-query tiles: this lane's query of tile qt is wc * 64 + qt * 16 + l15
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int q = hq * 256 + wc * 64 + ni * 32 + l31;
-        tauv[ni] = q < p.n_q ? p.tau[q] : __builtin_inff();
+    for (int qt = 0; qt < 4; ++qt) {
+        const int q = hq * 256 + wc * 64 + qt * 16 + (lane & 15);
+        tauv[qt] = q < p.n_q ? p.tau[q] : __builtin_inff();
 #ifdef EMDR2_EXPERIMENTS
-        if (p.tune & 128) tauv[ni] = __builtin_inff();        // timing experiment: the filter never fires
+        if (p.tune & 128) tauv[qt] = __builtin_inff();        // timing experiment: the filter never fires
 #endif
     }
 
@@ -146,34 +148,36 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         }                                                                                                                                 \
     } while (0)
 
-    // ---- fragment reads: lane reads row l31 of a 32-row block, 16-byte group ((ks & 1) * 2 + hi) ^ ((row >> 2) & 3) of chunk ks >> 1
-    const int swz = (l31 >> 2) & 3;
-    int a_rd[4], b_rd[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int g = ((((ks & 1) * 2 + hi) ^ swz) << 4);
-        a_rd[ks] = wr * 8192 + (ks >> 1) * 4096 + l31 * 64 + g;
-        b_rd[ks] = wc * 4096 + (ks >> 1) * 2048 + l31 * 64 + g;
-    }
-    half8 av[2][4], b0v[4], b1v[4];
+    // ---- fragment reads for v_mfma_f32_16x16x32_f16: a lane holds row (query) l15 of a 16-row tile and k = 8 lq .. 8 lq + 7 of the 32-wide
+    // chunk, i.e. the 16-byte group lq ^ ((row >> 2) & 3) of that row's 64 bytes.  r04: the 16 x 16 x 32 shape instead of 32 x 32 x 16 -- same
+    // fragment bytes and registers per flop, half the accumulator registers read and written per flop: with N(0,1) operands an MFMA-only loop
+    // sustains 2,120 instead of 1,780 TFLOP/s at the board's power cap (tools/mfma_peak.hip), and the cap is what binds this kernel.
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int frag_rd = l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4);
+    const int a_rd = wr * 8192 + frag_rd;                       // + chunk * 4096 + row tile * 1024
+    const int b_rd = wc * 4096 + frag_rd;                       // + chunk * 2048 + query tile * 1024
+    half8 av[2][4], b0v[4], b1v[4];                              // A: [chunk][16-row tile of the 64-row half]; B: [chunk * 2 + 16-query tile of the 32-query half]
 #define S8_READ_A(BUF, MH)                                                                                                                \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                         \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
-            av[f][ks] = *(const half8 *)(smem + (BUF) * S8_BUF + ((MH) ? 3 * S8_SLOT : 0) + f * 2048 + a_rd[ks])
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            av[c][rt] = *(const half8 *)(smem + (BUF) * S8_BUF + ((MH) ? 3 * S8_SLOT : 0) + c * 4096 + rt * 1024 + a_rd)
 #define S8_READ_B(BUF, NH, DST)                                                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        DST[ks] = *(const half8 *)(smem + (BUF) * S8_BUF + ((NH) ? 2 * S8_SLOT : S8_SLOT) + b_rd[ks])
-    // rows of the MFMA result = index rows (A fragment first), columns = queries: a lane holds ONE query and 16 rows per accumulator block
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                                  \
+            DST[2 * c + ct] = *(const half8 *)(smem + (BUF) * S8_BUF + ((NH) ? 2 * S8_SLOT : S8_SLOT) + c * 2048 + ct * 1024 + b_rd)
+    // rows of the MFMA result = index rows (A fragment first), columns = queries: a lane holds ONE query and 4 rows per accumulator tile
 #define S8_MFMA(MH, NH, BV)                                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[f][ks], BV[ks], acc[2 * (MH) + f][NH], 0, 0, 0)
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                              \
+                acc[4 * (MH) + rt][2 * (NH) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[c][rt], BV[2 * c + ct], acc[4 * (MH) + rt][2 * (NH) + ct], 0, 0, 0)
 // first K-tile of a row tile: each accumulator's first MFMA takes C = 0 as an inline constant -- the accumulators are never cleared by
 // separate instructions (128 v_mov per wave and item otherwise, inside the filter's VALU time)
 #define S8_MFMA_Z(MH, NH, BV)                                                                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_f16(av[f][ks], BV[ks], ks == 0 ? zero16 : acc[2 * (MH) + f][NH], 0, 0, 0)
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                              \
+                acc[4 * (MH) + rt][2 * (NH) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(av[c][rt], BV[2 * c + ct], c == 0 ? zero4 : acc[4 * (MH) + rt][2 * (NH) + ct], 0, 0, 0)
 #define S8_SYNC_COMPUTE(BETWEEN, MFMAS)                                                                                                   \
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
@@ -225,8 +229,8 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         if (!(P.s.tune & 64)) for (int i_ = 0; i_ < (lead_ > 6 ? 6 : lead_) - 1; ++i_) __builtin_amdgcn_s_sleep(16);     /* 1,024 cycles each */ \
     }
 
-    floatx16 acc[4][2];
-    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    floatx4 acc[8][4];                                         // [16-row tile of the wave's 128 rows][16-query tile of its 64 queries]
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
 #ifdef EMDR2_EXPERIMENTS
     if (hq == 1) for (int i = 0; i < P.s.tune >> 8; ++i) __builtin_amdgcn_s_sleep(32);      // EMDR2_MIPS_TUNE bits 8..: late start of the second half, 2,048 cycles each
@@ -292,49 +296,43 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         const int tile = P.t_begin + (P.halves == 2 ? pos >> 1 : pos);
         // lane ids rebuilt per item (v_mbcnt): hoisted to kernel entry they would be live across the whole main loop
         const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const int e31 = elane & 31, ehi = elane >> 5;
-        const int row_w = tile * 256 + wr * 128 + 4 * ehi;    // + 64 mh + 32 f + (r & 3) + 8 (r >> 2)
+        const int e15 = elane & 15, eq = elane >> 4;
+        const int row_w = tile * 256 + wr * 128 + 4 * eq;     // + 16 rt + r
         const bool tail = (tile + 1) * 256 > p.n_rows;          // only the shard's last tile has rows that do not exist
         bool stored = false;
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) {
-            const unsigned q = (unsigned)(hq * 256 + wc * 64 + ni * 32 + e31);
-            const float tau = tauv[ni];
-            // one max + one ballot per 32 x 32 accumulator block: a survivor sends its wave through the 16 registers of ONE block, not the 64 of a
-            // query column (1.6 survivors per item in the last segment; every slow path holds up the seven other waves at the next barrier)
+        for (int qt = 0; qt < 4; ++qt) {
+            const unsigned q = (unsigned)(hq * 256 + wc * 64 + qt * 16 + e15);
+            const float tau = tauv[qt];
+            // one max + one ballot per 128 x 16 accumulator column (31 v_max): the common case has no survivor.  A column with one looks into the
+            // 16 x 16 tiles that hold one (their maxes are the partial results of the column's) and there into the four registers.
+            float mr[8];
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                // the block's max as four quarter maxes (same 15 v_max): a block with a survivor then looks only into the quarters that hold one
-                float mq[4];
+            for (int rt = 0; rt < 8; ++rt) mr[rt] = fmaxf(fmaxf(acc[rt][qt][0], acc[rt][qt][1]), fmaxf(acc[rt][qt][2], acc[rt][qt][3]));
+            const float m = fmaxf(fmaxf(fmaxf(mr[0], mr[1]), fmaxf(mr[2], mr[3])), fmaxf(fmaxf(mr[4], mr[5]), fmaxf(mr[6], mr[7])));
+            if (__builtin_amdgcn_ballot_w64(m >= tau) == 0) continue;              // the common case
+            // Slots come out of this wave's OWN queue region: the reservation is a scalar add (r03: a ballot, an LDS atomic by lane 0 and a
+            // readfirstlane round trip per register that held a survivor); registers without a survivor cost a compare and a scalar branch.
 #pragma unroll
-                for (int g = 0; g < 4; ++g) mq[g] = fmaxf(fmaxf(acc[mi][ni][4 * g], acc[mi][ni][4 * g + 1]), fmaxf(acc[mi][ni][4 * g + 2], acc[mi][ni][4 * g + 3]));
-                const float m = fmaxf(fmaxf(mq[0], mq[1]), fmaxf(mq[2], mq[3]));
-                if (__builtin_amdgcn_ballot_w64(m >= tau) == 0) continue;          // the common case
-                // a block with survivors.  Slots come out of this wave's OWN queue region: the reservation is a scalar add (r03: a ballot, an LDS
-                // atomic by lane 0 and a readfirstlane round trip per register that held a survivor -- most of the filter's cost while the
-                // threshold is still loose); registers without a survivor cost a compare and a scalar branch.
+            for (int rt = 0; rt < 8; ++rt) {
+                if (__builtin_amdgcn_ballot_w64(mr[rt] >= tau) == 0) continue;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    if (__builtin_amdgcn_ballot_w64(mq[g] >= tau) == 0) continue;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const int r = 4 * g + e;
-                        const float v = acc[mi][ni][r];
-                        const int row = row_w + mi * 32 + (r & 3) + 8 * (r >> 2);
-                        const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
-                        if (mask == 0) continue;
-                        if ((mask >> elane) & 1ull) {
-                            const unsigned mine = wq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
-                            if (mine < S8_WCAP) {                                  // (two writes: no aligned register quad to assemble)
-                                ((uint2 *)qbuf)[2 * (wave * S8_WCAP + mine)] = make_uint2(__float_as_uint(v), (unsigned)row);
-                                ((unsigned *)qbuf)[4 * (wave * S8_WCAP + mine) + 2] = q;
-                            } else {                                               // queue region full: straight to the sub-list
-                                s8_append(p, xcc, q, __float_as_uint(v), (unsigned)row);
-                                stored = true;
-                            }
+                for (int r = 0; r < 4; ++r) {
+                    const float v = acc[rt][qt][r];
+                    const int row = row_w + rt * 16 + r;
+                    const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
+                    if (mask == 0) continue;
+                    if ((mask >> elane) & 1ull) {
+                        const unsigned mine = wq + __builtin_amdgcn_mbcnt_hi((unsigned)(mask >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)mask, 0));
+                        if (mine < S8_WCAP) {                                  // (two writes: no aligned register quad to assemble)
+                            ((uint2 *)qbuf)[2 * (wave * S8_WCAP + mine)] = make_uint2(__float_as_uint(v), (unsigned)row);
+                            ((unsigned *)qbuf)[4 * (wave * S8_WCAP + mine) + 2] = q;
+                        } else {                                               // queue region full: straight to the sub-list
+                            s8_append(p, xcc, q, __float_as_uint(v), (unsigned)row);
+                            stored = true;
                         }
-                        wq += (unsigned)__popcll(mask);
                     }
+                    wq += (unsigned)__popcll(mask);
                 }
             }
         }
