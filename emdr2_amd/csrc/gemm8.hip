@@ -9,9 +9,11 @@
 // Structure (one workgroup of 8 waves per CU, walking its share of the 256 x 256 output tiles):
 //  * K-tile = 64: an LDS row is one full 128-byte line of the operand; two K-tile buffers of four 16 KiB half-tiles each
 //    (A rows for the first / second 64-row half of every wave's 128 output rows, B rows for the first / second 32 columns of its 64).
-//  * a wave owns 128 x 64 outputs = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16, computed as D^T (B fragment first): a lane then holds 4
-//    consecutive COLUMNS of one output row per register group, so the epilogue packs bf16 pairs without cross-lane traffic.
-//  * four phases per K-tile, one C quadrant (64 x 32) x K = 64 each: 8 MFMAs behind 12 / 4 / 8 / 0 fragment reads; every phase also issues
+//  * a wave owns 128 x 64 outputs = 8 x 4 accumulators of v_mfma_f32_16x16x32_bf16 (r04; 4 x 2 of the 32 x 32 x 16 shape before: same
+//    fragment traffic, half the accumulator registers moved per flop, and at the board's power cap the 16 x 16 x 32 shape sustains 19 % more
+//    flops, tools/mfma_peak.hip), computed as D^T (B fragment first): a lane then holds 4 consecutive COLUMNS of one output row per
+//    accumulator, so the epilogue packs bf16 pairs without cross-lane traffic.
+//  * four phases per K-tile, one C quadrant (64 x 32) x K = 64 each: 16 MFMAs behind 12 / 4 / 8 / 0 fragment reads; every phase also issues
 //    one half-tile of LDS-DMA (2 x 1 KiB per wave) SIX half-tiles ahead of its consumer and waits with a counted vmcnt(8); a half-tile's slot is
 //    re-used two or three phases after its last read, which is what lets two buffers run a prefetch distance of more than one K-tile.
 //  * waves 0-3 and 4-7 (one of each per SIMD) run ONE BARRIER APART: while one half issues its MFMAs the other issues its LDS reads and DMA,
@@ -135,33 +137,38 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
         }                                                                                                                                 \
     } while (0)
 
-    // ---- fragment read addressing: lane reads row l31 of a 32-row fragment, 16-B group (2 ks + hi) ^ ((row >> 1) & 7)
-    int a_rd[4], b_rd[4];
+    // ---- fragment read addressing (v_mfma_f32_16x16x32_bf16): lane reads row l15 of a 16-row fragment, k = 32 c + 8 lq .. + 7 of the K-tile,
+    // i.e. the 16-B group (4 c + lq) ^ ((row >> 1) & 7)
+    const int l15 = lane & 15, lq = lane >> 4;
+    int a_rd[2], b_rd[2];
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-        const int g = ((ks * 2 + hi) ^ ((l31 >> 1) & 7)) << 4;
-        a_rd[ks] = (wr * 64 + l31) * 128 + g;
-        b_rd[ks] = (wc * 32 + l31) * 128 + g;
+    for (int c = 0; c < 2; ++c) {
+        const int g = ((4 * c + lq) ^ ((l15 >> 1) & 7)) << 4;
+        a_rd[c] = (wr * 64 + l15) * 128 + g;                      // + 16-row tile * 2048
+        b_rd[c] = (wc * 32 + l15) * 128 + g;
     }
-    bf16x8 av[2][4], b0v[4], b1v[4];
+    bf16x8 av[2][4], b0v[4], b1v[4];                              // A: [k half][16-row tile of the 64-row half]; B: [k half * 2 + 16-column tile of the 32-column half]
 #define G8_READ_A(BUF, MH)                                                                                                                \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                         \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
-            av[f][ks] = *(const bf16x8 *)(smem + (BUF) * G8_BUF + ((MH) ? 3 * G8_SLOT : 0) + f * 4096 + a_rd[ks])
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            av[c][rt] = *(const bf16x8 *)(smem + (BUF) * G8_BUF + ((MH) ? 3 * G8_SLOT : 0) + rt * 2048 + a_rd[c])
 #define G8_READ_B(BUF, NH, DST)                                                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        DST[ks] = *(const bf16x8 *)(smem + (BUF) * G8_BUF + ((NH) ? 2 * G8_SLOT : G8_SLOT) + b_rd[ks])
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                                  \
+            DST[2 * c + ct] = *(const bf16x8 *)(smem + (BUF) * G8_BUF + ((NH) ? 2 * G8_SLOT : G8_SLOT) + ct * 2048 + b_rd[c])
     // D^T orientation: rows of the MFMA result = columns n of C (B fragment first), its columns = rows m of C
 #define G8_MFMA(MH, NH, BV)                                                                                                               \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV[ks], av[f][ks], acc[2 * (MH) + f][NH], 0, 0, 0)
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                              \
+                acc[4 * (MH) + rt][2 * (NH) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BV[2 * c + ct], av[c][rt], acc[4 * (MH) + rt][2 * (NH) + ct], 0, 0, 0)
 // first K-tile of an output tile: each accumulator's first MFMA takes C = 0 as an inline constant, so the accumulators are never cleared by
 // separate instructions (128 v_mov per wave and tile otherwise, paid inside the VALU-bound epilogues)
 #define G8_MFMA_Z(MH, NH, BV)                                                                                                             \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(BV[ks], av[f][ks], ks == 0 ? zero16 : acc[2 * (MH) + f][NH], 0, 0, 0)
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                              \
+                acc[4 * (MH) + rt][2 * (NH) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(BV[2 * c + ct], av[c][rt], c == 0 ? zero4 : acc[4 * (MH) + rt][2 * (NH) + ct], 0, 0, 0)
 #define G8_SYNC_COMPUTE(MFMAS) G8_SYNC_COMPUTE_W(asm volatile("s_waitcnt vmcnt(8)" ::: "memory"), MFMAS)
 // first K-tile after a tile seam: the epilogue's stores sit in the (in-order) vmcnt queue between the DMA issued before the seam and the
 // DMA issued now.  "All DMA except the newest four half-tiles has landed" is then vmcnt(8 + stores): the write-backs of the previous
@@ -182,8 +189,8 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
     __builtin_amdgcn_s_barrier();                                                                                                         \
     __builtin_amdgcn_sched_barrier(0)
 
-    floatx16 acc[4][2];
-    const floatx16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    floatx4 acc[8][4];                                          // [16-row tile of the wave's 128 rows][16-column tile of its 64 columns]
+    const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // ---- XCD stagger.  Every tile takes the same time, so without this all 256 CUs reach their epilogues together and 33 MB of output hits
     // the memory system as one burst per tile period (the store issue then stalls for microseconds).  XCD x starts x/8 of a tile period late:
@@ -261,16 +268,16 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
         // lane-derived epilogue addresses are rebuilt per tile from a fresh lane id (v_mbcnt): hoisted to kernel entry they would be
         // live across the whole main loop and push its operands into scratch
         const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-        const int e31 = elane & 31, ehi = elane >> 5;
+        const int e15 = elane & 15, eq = elane >> 4;             // accumulator order: C row e15 of a 16-row tile, columns 4 eq .. 4 eq + 3 of a 16-column tile
         char *stg = smem + G8_STAGING + wave * 4096;            // wave-private: 32 rows x 64 bf16, 8-B slots XOR-swizzled with (row & 15)
         const int prow = elane >> 3, pc16 = elane & 7;           // row-order pass: 8 lanes cover one 128-byte row segment, 8 rows per pass
 
 #ifdef EMDR2_EXPERIMENTS
         if (p.ablate == 1) {
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi)
+            for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
+                for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
             if (wr == 1) { G8_BARRIER(); }
             continue;
         }
@@ -287,15 +294,13 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
             const long long pitch8 = p.ldc * 16;                  // bytes per 8 rows
             // bias of the 32 columns this lane holds in accumulator order: loaded ONCE per tile and BEFORE the residual rows (vmcnt retires
             // in order: a bias load issued behind them would make its first use wait for the whole residual block)
-            float bcol[2][16];
+            float bcol[4][4];                                     // [16-column tile][register]
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if constexpr (HAS_BIAS) t = *(const float4 *)(p.bias + n_w + ni * 32 + 8 * j + 4 * ehi);
-                    bcol[ni][4 * j] = t.x; bcol[ni][4 * j + 1] = t.y; bcol[ni][4 * j + 2] = t.z; bcol[ni][4 * j + 3] = t.w;
-                }
+            for (int nt = 0; nt < 4; ++nt) {
+                float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (HAS_BIAS) t = *(const float4 *)(p.bias + n_w + nt * 16 + 4 * eq);
+                bcol[nt][0] = t.x; bcol[nt][1] = t.y; bcol[nt][2] = t.z; bcol[nt][3] = t.w;
+            }
             // residual rows in row order, fetched as far ahead as the registers allow: a slab is staged in ~0.7 us, a residual row takes 1-2 us
             // to arrive -- two slabs ahead (r02) every slab still waited for its rows.  All four at once where 64 registers are free (the
             // main loop's operand registers are, the dropout recipe's hash temporaries leave room for three)
@@ -314,50 +319,53 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m_l = m_w + mi * 32 + e31;              // the C row this lane holds in accumulator order
-                float act[PREG ? 2 : 1][16];                      // PREG: the activations wait here while their derivatives go out in pass 0
+                float act[PREG ? 8 : 1][4];                       // PREG: the activations wait here while their derivatives go out in pass 0
 #pragma unroll
                 for (int pass = 0; pass < npass; ++pass) {
                     const bool final_pass = pass == npass - 1;
+                    // a 32-row slab = two 16-row accumulator tiles (h) x four 16-column tiles (nt); this lane: slab row 16 h + e15
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        float v[16];
-                        if constexpr (PREG) {
-                            if (pass == 0) {
+                    for (int h = 0; h < 2; ++h) {
+                        const int srow = 16 * h + e15;
+                        const int m_l = m_w + mi * 32 + srow;             // the C row this lane holds in accumulator order
+                        uint32_t rh = 0;
+                        if constexpr ((EPI & G8_DROP) != 0) rh = emdr2_row_hash(p.seed, (unsigned long long)m_l);
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) act[ni][r] = gelu_erf_with_grad(fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]), v[r]);
+                        for (int nt = 0; nt < 4; ++nt) {
+                            const floatx4 &a4 = acc[2 * mi + h][nt];
+                            float v[4];
+                            if constexpr (PREG) {
+                                if (pass == 0) {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) act[4 * h + nt][r] = gelu_erf_with_grad(fmaf(a4[r], p.alpha, bcol[nt][r]), v[r]);
+                                } else {
+#pragma unroll
+                                    for (int r = 0; r < 4; ++r) v[r] = act[4 * h + nt][r];
+                                }
                             } else {
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) v[r] = act[ni][r];
+                                for (int r = 0; r < 4; ++r) v[r] = fmaf(a4[r], p.alpha, bcol[nt][r]);
                             }
-                        } else {
+                            if (final_pass && !PREG) {
+                                if constexpr ((EPI & G8_GELU) != 0) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) v[r] = fmaf(acc[mi][ni][r], p.alpha, bcol[ni][r]);
-                        }
-                        if (final_pass && !PREG) {
-                            if constexpr ((EPI & G8_GELU) != 0) {
+                                    for (int r = 0; r < 4; ++r) v[r] = gelu_erf(v[r]);
+                                }
+                                if constexpr ((EPI & G8_DROP) != 0) {
+                                    // (col >> 1) * MUL of this lane's first pair of the tile; the second pair is the next one
+                                    const uint32_t prod0 = (uint32_t)((n_w + nt * 16 + 4 * eq) >> 1) * EMDR2_PAIR_MUL;
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) v[r] = gelu_erf(v[r]);
-                            }
-                            if constexpr ((EPI & G8_DROP) != 0) {
-                                const uint32_t rh = emdr2_row_hash(p.seed, (unsigned long long)m_l);
-                                // (col >> 1) * MUL of this lane's first pair; the other seven pairs are constant offsets from it
-                                const uint32_t prod0 = (uint32_t)((n_w + ni * 32 + 4 * ehi) >> 1) * EMDR2_PAIR_MUL;
-#pragma unroll
-                                for (int r = 0; r < 16; r += 2) {
-                                    const uint32_t bits = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)((8 * (r >> 2) + (r & 3)) >> 1) * EMDR2_PAIR_MUL);
-                                    // a multiplicative mask (not a select on v): keeps the compiler from predicating the loads v depends on
-                                    v[r] *= (bits & 0xffffu) >= thr ? keep_scale : 0.f;
-                                    v[r + 1] *= (bits >> 16) >= thr ? keep_scale : 0.f;
+                                    for (int r = 0; r < 4; r += 2) {
+                                        const uint32_t bits = emdr2_pair_bits_prod(rh, prod0 + (uint32_t)(r >> 1) * EMDR2_PAIR_MUL);
+                                        // a multiplicative mask (not a select on v): keeps the compiler from predicating the loads v depends on
+                                        v[r] *= (bits & 0xffffu) >= thr ? keep_scale : 0.f;
+                                        v[r + 1] *= (bits >> 16) >= thr ? keep_scale : 0.f;
+                                    }
                                 }
                             }
-                        }
-                        // accumulator order -> LDS: 4 consecutive columns = one 8-byte slot
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c8 = ni * 8 + 2 * j + ehi;
-                            *(uint2 *)(stg + e31 * 128 + ((c8 ^ (e31 & 15)) << 3)) =
-                                make_uint2(pack2_bf16(v[4 * j], v[4 * j + 1]), pack2_bf16(v[4 * j + 2], v[4 * j + 3]));
+                            // accumulator order -> LDS: 4 consecutive columns = one 8-byte slot
+                            const int c8 = nt * 4 + eq;
+                            *(uint2 *)(stg + srow * 128 + ((c8 ^ (srow & 15)) << 3)) = make_uint2(pack2_bf16(v[0], v[1]), pack2_bf16(v[2], v[3]));
                         }
                     }
                     asm volatile("" ::: "memory");                       // compiler fence only: the LDS executes one wave's writes and reads in order
@@ -393,37 +401,38 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                 }
             }
         } else {
-            // ---- LSE mode: logits = alpha * acc + bias stay in registers.  Per C row (one lane pair e31 / e31+32 holds its 64 columns of this
+            // ---- LSE mode: logits = alpha * acc + bias stay in registers.  Per C row (four lanes e15 + 16 eq hold its 64 columns of this
             // wave): max, sum exp(x - max), and the gold logit if the row's label falls into these columns.  The four waves of a row block
             // (wc = 0..3) write separate partials: slot index tn * 4 + wc of a [M, tiles_n * 4] table.
             const int nslots = p.tiles_n * 4;
 #pragma unroll
-            for (int mi = 0; mi < 4; ++mi) {
-                const int m_l = m_w + mi * 32 + e31;
+            for (int mt = 0; mt < 8; ++mt) {                      // 16-row accumulator tiles; four lanes (eq = 0..3) share a C row
+                const int m_l = m_w + mt * 16 + e15;
                 const long long lab = p.labels[m_l];
                 float mx = -3.0e38f, gold = 0.f;
                 bool has = false;
-                float x[2][16];
+                float x[4][4];
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int n = n_w + ni * 32 + 8 * (r >> 2) + 4 * ehi + (r & 3);
+                    for (int r = 0; r < 4; ++r) {
+                        const int n = n_w + nt * 16 + 4 * eq + r;
                         // the logits the unfused path would have stored are bf16: round the same way so both paths agree to the bit
-                        const float t = bf16_to_f32(f32_to_bf16(acc[mi][ni][r] * p.alpha + (HAS_BIAS ? p.bias[n] : 0.f)));
-                        x[ni][r] = t;
+                        const float t = bf16_to_f32(f32_to_bf16(acc[mt][nt][r] * p.alpha + (HAS_BIAS ? p.bias[n] : 0.f)));
+                        x[nt][r] = t;
                         mx = fmaxf(mx, t);
                         if ((long long)n == lab) { gold = t; has = true; }
                     }
-                const float mo = __shfl_xor(mx, 32);
-                mx = fmaxf(mx, mo);
+                mx = fmaxf(mx, __shfl_xor(mx, 16));
+                mx = fmaxf(mx, __shfl_xor(mx, 32));
                 float sm = 0.f;
 #pragma unroll
-                for (int ni = 0; ni < 2; ++ni)
+                for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) sm += __builtin_amdgcn_exp2f((x[ni][r] - mx) * 1.4426950408889634f);
+                    for (int r = 0; r < 4; ++r) sm += __builtin_amdgcn_exp2f((x[nt][r] - mx) * 1.4426950408889634f);
+                sm += __shfl_xor(sm, 16);
                 sm += __shfl_xor(sm, 32);
-                if (ehi == 0) {
+                if (eq == 0) {
                     p.lse_max[(long long)m_l * nslots + tn * 4 + wc] = mx;
                     p.lse_sum[(long long)m_l * nslots + tn * 4 + wc] = sm;
                 }
