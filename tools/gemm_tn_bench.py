@@ -1,10 +1,13 @@
 """Weight-gradient GEMM (TN, LDS transpose reads) timing at the reader's shapes (GPU)."""
+import os
 import sys
 import time
 
 import torch
 
 from emdr2_amd import _native
+if "--lib" in sys.argv:                                     # A/B of two builds: --lib path/to/libemdr2_hip.so
+    _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
 if "--exp" in sys.argv:                                     # the experiments build (make -C emdr2_amd/csrc exp): EMDR2_T8_ABLATE, EMDR2_TN_OLD
     _native.LIB_PATH = _native.LIB_PATH.replace("libemdr2_hip.so", "libemdr2_hip_exp.so")
 from emdr2_amd.model import kernels as K
