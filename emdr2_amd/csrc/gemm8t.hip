@@ -5,8 +5,8 @@
 //
 // Reference op: the autograd weight gradient of F.linear (megatron/mpu/layers.py:255,353) = dy^T x, R = 1.6M tokens in the EMDR2 step.
 //
-// What carries over from gemm8.hip: the 256 x 256 output tile held by 8 waves (2 x 4, 128 x 64 outputs = 4 x 2 accumulators each), K-tile = 64
-// reduction rows as four 16 KiB half-tiles (A0, B0, B1, A1) re-used half-tile by half-tile, four phases per K-tile with 8 MFMAs each behind
+// What carries over from gemm8.hip: the 256 x 256 output tile held by 8 waves (2 x 4, 128 x 64 outputs = 8 x 4 accumulators of the 16 x 16 x 32
+// MFMA shape each), K-tile = 64 reduction rows as four 16 KiB half-tiles (A0, B0, B1, A1) re-used half-tile by half-tile, four phases per K-tile with 16 MFMAs each behind
 // one half-tile of LDS-DMA and a counted vmcnt, the two wave halves one barrier apart.
 // What differs:
 //  * the operands arrive with the REDUCTION index slow.  A half-tile is [64 r][128 columns]: full 256-byte rows straight from the activation
@@ -20,10 +20,6 @@
 //  * work item = (reduction slice, output tile), one per workgroup, tile index fastest and an XCD-contiguous item range: the tiles that stream
 //    the same token rows run together on one L2; slices are interleaved K-tile by K-tile.  The epilogue is 128 fp32 atomics (or plain stores,
 //    one slice) per wave once per ~900 K-tiles: no persistence needed.
-//  * the MFMA shape stays 32 x 32 x 16.  The 16 x 16 x 32 shape that gemm8.hip and mips_scan8.hip moved to in r04 (19 % more flops per watt in
-//    an MFMA-only loop) was built here too (transposed reads of 4 x 16 blocks per 16-lane group, 8 x 4 accumulators) and measures the same
-//    in isolation (1,121 vs 1,122 TFLOP/s at dW[3072, 768]) and 2.5 % SLOWER inside the step (314 -> 322 ms): this kernel is bound by its
-//    operand feed (every byte a fresh HBM line through the L1's request slots), not by the power cap.
 //  * optional bias gradient: colsum[i] += sum_r A[r, i], from the A fragments of the waves wc == 0 of the tj == 0 tiles (v_dot2_f32_bf16
 //    against ones: four VALU ops per fragment).
 #include "../../include/emdr2_ops.h"
@@ -58,8 +54,7 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;                 // wave grid 2 (i) x 4 (j); wr is also the half that runs one barrier behind
-    const int l31 = lane & 31, hi = lane >> 5;
-    const int t = lane & 15, colgrp = (lane >> 4) & 1;
+    const int t = lane & 15, lq = lane >> 4;                  // v_mfma_f32_16x16x32_bf16: fragment column t, k = 8 lq .. 8 lq + 7 of a 32-row k-step
 
     // ---- this workgroup's item: XCD x = id & 7 owns items [x * per_xcd, (x + 1) * per_xcd), tile index fastest inside a slice
     const int per_xcd = (p.items + 7) >> 3;
@@ -74,9 +69,11 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     const long long lda2 = p.lda * 2, ldb2 = p.ldb * 2;
 
     // ---- LDS-DMA addressing.  A half-tile is 64 LDS rows of 256 B; a DMA instruction writes 4 rows (lane -> row lane >> 4, 16-B slot lane & 15);
-    // wave w fills rows [4w, 4w + 4) and [32 + 4w, 32 + 4w + 4).  Slot s of row r holds source granule s ^ ((r & 3) << 2).
+    // wave w fills rows [4w, 4w + 4) and [32 + 4w, 32 + 4w + 4).  Slot s of row r holds source granule s ^ ((r & 3) << 2) ^ (((r >> 3) & 1) << 1).
     const int dr = lane >> 4;
-    const int gsrc = (lane & 15) ^ (dr << 2);
+    // (r04: rows 8 apart -- the two 16-lane groups of a 32-lane service group of the 16 x 16 x 32 fragment reads -- additionally swap the two
+    // 32-byte halves of a 64-byte slot: row r = 4 wave + dr (+ 32) has (r >> 3) & 1 = (wave >> 1) & 1)
+    const int gsrc = (lane & 15) ^ (dr << 2) ^ (((wave >> 1) & 1) << 1);
     uint32_t offA[2], offB[2];                                // half-tile h: columns [128 h, 128 h + 128) of the tile
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -117,38 +114,41 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
         if ((T) == 3 && s_kt + 1 < KT_STREAM) { ++s_kt; sA += hopA; sB += hopB; }   /* past the end: harmless re-reads of the last K-tile */ \
     } while (0)
 
-    // ---- transposed fragment reads: lane (t, colgrp, hi) addresses row 8 hi + (t >> 2) (+ 4 for the second read) of a 16-row k-step and the
-    // 8-byte run of columns colgrp * 16 + (t & 3) * 4; it receives column colgrp * 16 + t = lane & 31 of the 32-column fragment.
-    const int rbase = 8 * hi + (t >> 2), sw = (t >> 2) << 2;
-    uint32_t a_rd[2], b_rd;
+    // (First version of this layout: the four 16-lane groups read the SAME 32-byte column run of rows 8 apart, which the (r & 3) swizzle maps
+    // to the same banks -- a 2-way conflict inside every 32-lane service group that cost exactly what the MFMA shape gained: equal to the
+    // 32 x 32 x 16 kernel in isolation, 2.5 % slower in the step.  With the (r >> 3) & 1 term of the swizzle: +3.5-6 % per shape.)
+    // ---- transposed fragment reads (r04: for the 16 x 16 x 32 MFMA shape, see gemm8.hip): a 16-lane group addresses 4 rows x 16 columns --
+    // lane t: row (t >> 2), the 8-byte run of columns (t & 3) * 4 -- and lane t receives column t of those four rows; the four groups of a wave
+    // take rows 8 lq .. 8 lq + 3 (and + 4 for the second read) of a 32-row k-step, all of the same 16-column fragment.
+    const int rbase = 8 * lq + (t >> 2), sw = ((t >> 2) << 2) ^ ((lq & 1) << 1);
+    uint32_t a_rd[4], b_rd[2];
 #pragma unroll
-    for (int f = 0; f < 2; ++f) {
-        const int col = wr * 64 + f * 32 + colgrp * 16 + (t & 3) * 4;
-        a_rd[f] = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
+    for (int rt = 0; rt < 4; ++rt) {
+        const int col = wr * 64 + rt * 16 + (t & 3) * 4;
+        a_rd[rt] = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
     }
-    {
-        const int col = wc * 32 + colgrp * 16 + (t & 3) * 4;
-        b_rd = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
+#pragma unroll
+    for (int ct = 0; ct < 2; ++ct) {
+        const int col = wc * 32 + ct * 16 + (t & 3) * 4;
+        b_rd[ct] = rbase * 256 + (((col >> 3) ^ sw) << 4) + (col & 7) * 2;
     }
     // Fragment halves as raw 8-byte pairs.  The reads are inline asm on purpose: for the ds_read_tr builtin the compiler's wait-count pass
     // assumes the read may alias every LDS-DMA in flight and puts s_waitcnt vmcnt(0) in front of it -- in every phase, which collapsed the
     // eight-half-tile DMA pipeline to one (the first versions of this kernel ran like that).  The matching lgkmcnt wait is T8_WAIT_* below.
-    uint2 al[2][4], ah[2][4], b0l[4], b0h[4], b1l[4], b1h[4];
+    uint2 al[2][4], ah[2][4], b0l[4], b0h[4], b1l[4], b1h[4];  // A: [k half][16-column tile of the 64-column block]; B: [k half * 2 + 16-column tile of the 32]
     int rd_off = 0;                                           // ring offset of the current K-tile's A0; B0, B1, A1 follow (with wrap-around)
     auto ring = [](int off) { return off >= T8_RING ? off - T8_RING : off; };
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
 #define T8_TR(dst, addr, off) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(dst) : "v"(addr), "n"(off))
 #define T8_READ_A(SLOT)                                                                                                                   \
-    _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                                                                       \
-        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + a_rd[f];                                                \
-        T8_TR(al[f][0], base_, 0); T8_TR(ah[f][0], base_, 1024); T8_TR(al[f][1], base_, 4096); T8_TR(ah[f][1], base_, 5120);              \
-        T8_TR(al[f][2], base_, 8192); T8_TR(ah[f][2], base_, 9216); T8_TR(al[f][3], base_, 12288); T8_TR(ah[f][3], base_, 13312);         \
+    _Pragma("unroll") for (int rt = 0; rt < 4; ++rt) {                                                                                    \
+        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + a_rd[rt];                                               \
+        T8_TR(al[0][rt], base_, 0); T8_TR(ah[0][rt], base_, 1024); T8_TR(al[1][rt], base_, 8192); T8_TR(ah[1][rt], base_, 9216);          \
     }
 #define T8_READ_B(SLOT, L, H)                                                                                                             \
-    {                                                                                                                                     \
-        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + b_rd;                                                   \
-        T8_TR(L[0], base_, 0); T8_TR(H[0], base_, 1024); T8_TR(L[1], base_, 4096); T8_TR(H[1], base_, 5120);                              \
-        T8_TR(L[2], base_, 8192); T8_TR(H[2], base_, 9216); T8_TR(L[3], base_, 12288); T8_TR(H[3], base_, 13312);                         \
+    _Pragma("unroll") for (int ct = 0; ct < 2; ++ct) {                                                                                    \
+        const uint32_t base_ = lds0 + (uint32_t)ring(rd_off + (SLOT) * T8_SLOT) + b_rd[ct];                                               \
+        T8_TR(L[ct], base_, 0); T8_TR(H[ct], base_, 1024); T8_TR(L[2 + ct], base_, 8192); T8_TR(H[2 + ct], base_, 9216);                  \
     }
 #define T8_WAIT_A()                                                                                                                       \
     asm volatile("s_waitcnt lgkmcnt(0)"                                                                                                   \
@@ -158,11 +158,12 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
 #define T8_WAIT_B(L, H)                                                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(L[0]), "+v"(H[0]), "+v"(L[1]), "+v"(H[1]), "+v"(L[2]), "+v"(H[2]), "+v"(L[3]), "+v"(H[3])::"memory")
 #define T8_FR(L, H) __builtin_bit_cast(bf16x8, make_uint4((L).x, (L).y, (H).x, (H).y))
-    // rows of the MFMA result = i (A fragment first), columns = j: a lane holds one j and 16 i, so 32 lanes write 128 contiguous bytes of C
+    // rows of the MFMA result = i (A fragment first), columns = j: a lane holds one j and 4 i, 16 lanes write 64 contiguous bytes of C
 #define T8_MFMA(MH, NH, BL, BH)                                                                                                           \
-    _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                      \
-        _Pragma("unroll") for (int f = 0; f < 2; ++f)                                                                                     \
-            acc[2 * (MH) + f][NH] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(T8_FR(al[f][ks], ah[f][ks]), T8_FR(BL[ks], BH[ks]), acc[2 * (MH) + f][NH], 0, 0, 0)
+    _Pragma("unroll") for (int c = 0; c < 2; ++c)                                                                                         \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            _Pragma("unroll") for (int ct = 0; ct < 2; ++ct)                                                                              \
+                acc[4 * (MH) + rt][2 * (NH) + ct] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(T8_FR(al[c][rt], ah[c][rt]), T8_FR(BL[2 * c + ct], BH[2 * c + ct]), acc[4 * (MH) + rt][2 * (NH) + ct], 0, 0, 0)
 #define T8_SYNC_COMPUTE(WAIT, MFMAS)                                                                                                      \
     asm volatile("s_waitcnt vmcnt(12)" ::: "memory");                                                                                     \
     __builtin_amdgcn_sched_barrier(0);                                                                                                    \
@@ -178,34 +179,35 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     __builtin_amdgcn_s_barrier();                                                                                                         \
     __builtin_amdgcn_sched_barrier(0)
 
-    floatx16 acc[4][2];
+    floatx4 acc[8][4];                                         // [16-column tile of the wave's 128 i][16-column tile of its 64 j]
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 8; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
-    float csum[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int r = 0; r < 4; ++r) acc[mi][ni][r] = 0.f;
+    float csum[2] = {0.f, 0.f};                               // [mh]: this wave sums the 16-column tile rt == wc of each 64-column block
     // Bias gradient colsum[i] += sum_r A[r, i].  Every A fragment must be summed exactly once across the tiles_j workgroups that read the same
-    // A columns and the four waves (wc) that hold the same fragments: K-tile kt belongs to the tile with tj == kt % tiles_j, k-step ks to the
-    // wave with wc == ks.  (The first version gave all of it to the wc == 0 waves of the tj == 0 tiles: 32 v_dot2 per K-tile on one wave in
-    // eight, at ~24 cycles apiece beside MFMAs -- those workgroups ran 26 % longer and the launch waits for its slowest workgroup.)
+    // A columns and the four waves (wc) that hold the same fragments: K-tile kt belongs to the tile with tj == kt % tiles_j, the 16-column
+    // tile rt of a 64-column block to the wave with wc == rt.  (The first version gave all of it to the wc == 0 waves of the tj == 0 tiles:
+    // 32 v_dot2 per K-tile on one wave in eight, at ~24 cycles apiece beside MFMAs -- those workgroups ran 26 % longer and the launch waits
+    // for its slowest workgroup.)
     const int tiles_j = p.tiles / p.tiles_i;
     const bool want_colsum = p.colsum != nullptr;             // wave-uniform
     int cs_phase = tj;                                        // counts down to this tile's K-tiles
     const bf16x2_t ones2 = __builtin_bit_cast(bf16x2_t, 0x3f803f80u);
 #define T8_COLSUM(MH)                                                                                                                     \
     if (want_colsum && cs_phase == 0) {                                                                                                   \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks)                                                                                  \
-            if (ks == wc) {                                                                                                               \
-                _Pragma("unroll") for (int f = 0; f < 2; ++f) {                                                                           \
-                    const uint4 w_ = make_uint4(al[f][ks].x, al[f][ks].y, ah[f][ks].x, ah[f][ks].y);                                      \
-                    float s_ = csum[2 * (MH) + f];                                                                                        \
+        _Pragma("unroll") for (int rt = 0; rt < 4; ++rt)                                                                                  \
+            if (rt == wc) {                                                                                                               \
+                _Pragma("unroll") for (int c = 0; c < 2; ++c) {                                                                           \
+                    const uint4 w_ = make_uint4(al[c][rt].x, al[c][rt].y, ah[c][rt].x, ah[c][rt].y);                                      \
+                    float s_ = csum[MH];                                                                                                  \
                     s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.x), ones2, s_, false);                           \
                     s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.y), ones2, s_, false);                           \
                     s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.z), ones2, s_, false);                           \
                     s_ = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, w_.w), ones2, s_, false);                           \
-                    csum[2 * (MH) + f] = s_;                                                                                              \
+                    csum[MH] = s_;                                                                                                        \
                 }                                                                                                                         \
             }                                                                                                                             \
     }
@@ -243,26 +245,27 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
     if (wr == 0) { T8_BARRIER(); }                            // the leading half pays back the barrier the trailing half took at the start
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // speculative half-tiles past the end of the stream
 
-    // ---- epilogue.  acc[2 mh + f][nh]: rows i = i0 + 128 mh + 64 wr + 32 f + (r & 3) + 8 (r >> 2) + 4 hi, column j = j0 + 128 nh + 32 wc + lane & 31
+    // ---- epilogue.  acc[4 mh + rt][2 nh + ct]: rows i = i0 + 128 mh + 64 wr + 16 rt + 4 lq + r, column j = j0 + 128 nh + 32 wc + 16 ct + t
     if (want_colsum) {
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const auto sw2 = __builtin_amdgcn_permlane32_swap(__float_as_uint(csum[mi]), __float_as_uint(csum[mi]), false, false);
-            const float tot = __uint_as_float(sw2[0]) + __uint_as_float(sw2[1]);
-            const int i = i0 + 128 * (mi >> 1) + 64 * wr + 32 * (mi & 1) + l31;
-            if (hi == 0 && i < p.I) unsafeAtomicAdd(&p.colsum[i], tot);
+        for (int mh = 0; mh < 2; ++mh) {
+            float tot = csum[mh];                                                       // the four k-groups of the wave hold partial sums of column t
+            tot += __shfl_xor(tot, 16);
+            tot += __shfl_xor(tot, 32);
+            const int i = i0 + 128 * mh + 64 * wr + 16 * wc + t;
+            if (lq == 0 && i < p.I) unsafeAtomicAdd(&p.colsum[i], tot);
         }
     }
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int j = j0 + 128 * ni + 32 * wc + l31;
+    for (int ni = 0; ni < 4; ++ni) {
+        const int j = j0 + 128 * (ni >> 1) + 32 * wc + 16 * (ni & 1) + t;
         if (j >= p.J) continue;
 #pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const int ib = i0 + 128 * (mi >> 1) + 64 * wr + 32 * (mi & 1) + 4 * hi;
+        for (int mi = 0; mi < 8; ++mi) {
+            const int ib = i0 + 128 * (mi >> 2) + 64 * wr + 16 * (mi & 3) + 4 * lq;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = ib + (r & 3) + 8 * (r >> 2);
+            for (int r = 0; r < 4; ++r) {
+                const int i = ib + r;
                 if (i >= p.I) continue;
                 float *dst = p.C + (long long)i * p.ldc + j;
                 if (p.atomic) unsafeAtomicAdd(dst, acc[mi][ni][r]);
