@@ -98,7 +98,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     float tauv[4];                                             // the wave's four 16-query tiles: this lane's query of tile qt is wc * 64 + qt * 16 + l15
 #pragma unroll
     for (int qt = 0; qt < 4; ++qt) {
-        const int q = hq * 256 + wc * 64 + qt * 16 + (lane & 15);
+        const int q = hq * 256 + wc * 64 + qt * 16 + ((lane & 3) * 4 + ((lane & 15) >> 2));      // (tile rows are permuted, see the fragment reads)
         tauv[qt] = q < p.n_q ? p.tau[q] : __builtin_inff();
 #ifdef EMDR2_EXPERIMENTS
         if (p.tune & 128) tauv[qt] = __builtin_inff();        // timing experiment: the filter never fires
@@ -152,8 +152,13 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     // chunk, i.e. the 16-byte group lq ^ ((row >> 2) & 3) of that row's 64 bytes.  r04: the 16 x 16 x 32 shape instead of 32 x 32 x 16 -- same
     // fragment bytes and registers per flop, half the accumulator registers read and written per flop: with N(0,1) operands an MFMA-only loop
     // sustains 2,120 instead of 1,780 TFLOP/s at the board's power cap (tools/mfma_peak.hip), and the cap is what binds this kernel.
+    // Operand lane l15 takes tile row prow = 4 (l15 & 3) + (l15 >> 2), not row l15: with consecutive rows on consecutive lanes every
+    // ds_read_b128 of this pattern has a 2-way bank conflict on the 64-byte-row image (SQ_LDS_BANK_CONFLICT = half of SQ_LDS_IDX_ACTIVE;
+    // tools/lds_conflict_probe.hip), with the rows of a tile dealt four apart none.  Output row m = 4 eq + r of a tile is then index row
+    // 4 r + eq, output column e15 query 4 (e15 & 3) + (e15 >> 2): the filter below and the thresholds above follow.
     const int l15 = lane & 15, lq = lane >> 4;
-    const int frag_rd = l15 * 64 + ((lq ^ ((l15 >> 2) & 3)) << 4);
+    const int prow = (l15 & 3) * 4 + (l15 >> 2);
+    const int frag_rd = prow * 64 + ((lq ^ ((prow >> 2) & 3)) << 4);
     const int a_rd = wr * 8192 + frag_rd;                       // + chunk * 4096 + row tile * 1024
     const int b_rd = wc * 4096 + frag_rd;                       // + chunk * 2048 + query tile * 1024
     half8 av[2][4], b0v[4], b1v[4];                              // A: [chunk][16-row tile of the 64-row half]; B: [chunk * 2 + 16-query tile of the 32-query half]
@@ -297,12 +302,12 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
         // lane ids rebuilt per item (v_mbcnt): hoisted to kernel entry they would be live across the whole main loop
         const int elane = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
         const int e15 = elane & 15, eq = elane >> 4;
-        const int row_w = tile * 256 + wr * 128 + 4 * eq;     // + 16 rt + r
+        const int row_w = tile * 256 + wr * 128 + eq;         // + 16 rt + 4 r
         const bool tail = (tile + 1) * 256 > p.n_rows;          // only the shard's last tile has rows that do not exist
         bool stored = false;
 #pragma unroll
         for (int qt = 0; qt < 4; ++qt) {
-            const unsigned q = (unsigned)(hq * 256 + wc * 64 + qt * 16 + e15);
+            const unsigned q = (unsigned)(hq * 256 + wc * 64 + qt * 16 + (e15 & 3) * 4 + (e15 >> 2));
             const float tau = tauv[qt];
             // one max + one ballot per 128 x 16 accumulator column (31 v_max): the common case has no survivor.  A column with one looks into the
             // 16 x 16 tiles that hold one (their maxes are the partial results of the column's) and there into the four registers.
@@ -319,7 +324,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float v = acc[rt][qt][r];
-                    const int row = row_w + rt * 16 + r;
+                    const int row = row_w + rt * 16 + 4 * r;
                     const unsigned long long mask = __builtin_amdgcn_ballot_w64((v >= tau) && (!tail || row < p.n_rows));
                     if (mask == 0) continue;
                     if ((mask >> elane) & 1ull) {

@@ -4,6 +4,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from emdr2_amd import _native
+if "--lib" in sys.argv:                                     # another build of the library (A/B)
+    _i = sys.argv.index("--lib"); _native.LIB_PATH = os.path.abspath(sys.argv[_i + 1]); del sys.argv[_i:_i + 2]
 if "--exp" in sys.argv:                                     # experiments build: EMDR2_MIPS_ABLATE / _KERNEL / _VARIANT switches are live
     _native.LIB_PATH = _native.LIB_PATH.replace("libemdr2_hip.so", "libemdr2_hip_exp.so")
     sys.argv.remove("--exp")
