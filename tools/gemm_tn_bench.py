@@ -5,6 +5,8 @@ import time
 
 import torch
 
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
 from emdr2_amd import _native
 if "--lib" in sys.argv:                                     # A/B of two builds: --lib path/to/libemdr2_hip.so
     _native.LIB_PATH = os.path.abspath(sys.argv[sys.argv.index("--lib") + 1])
