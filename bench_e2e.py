@@ -55,6 +55,10 @@ def add_args(ap):
     ap.add_argument("--selective-layers", default="auto",
                     help="encoder layers run with selective activation retention (6 of ~16 [tokens, h] tensors kept, FFN intermediates rebuilt in "
                          "the backward): 'auto' = reader encoder first, then the context tower, as HBM allows; or 'R,C' (reader, context tower)")
+    ap.add_argument("--micro-batches", type=int, default=-1,
+                    help="question micro-batches per step (EMDR2Model.forward_backward): the batch's questions run their post-search forward + "
+                         "backward in this many groups and NO layer is re-run in the backward (no --checkpoint-activations).  -1 = by top-k "
+                         "(4 up to 50, 8 above); 1 = the undivided step with per-layer recompute / selective retention (rounds 1-4)")
     ap.add_argument("--no-packing", action="store_true",
                     help="run the encoder stacks over the reference's padded [batch, S] grids instead of the packed real tokens (A/B)")
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
@@ -85,6 +89,11 @@ def setup(args, rank, world, index=None, topk=50):
     from emdr2_amd.model import kernels as Kmod
 
     B, K, S, S_ret = args.batch, topk, args.seq, args.seq_ret
+    micro = int(getattr(args, "micro_batches", -1))
+    if micro < 1:
+        micro = 4 if K <= 50 else 8
+        while B % micro:
+            micro //= 2
     Kmod.PACKING.enabled = not getattr(args, "no_packing", False)
     Kmod.PACKING.sticky, Kmod.PACKING.capacity = True, {}    # constant activation sizes from step to step (allocator reuse)
     Kmod.PREMASK.enabled = os.environ.get("EMDR2_PREMASK", "1") != "0"          # A/B switch: dropout masks of the backward from the LayerNorm backward (default) or their own launches
@@ -98,7 +107,7 @@ def setup(args, rank, world, index=None, topk=50):
     torch.manual_seed(1234)
     cfg = Config(num_layers=args.layers, hidden_size=H, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512, init_method_std=0.02,
                  hidden_dropout=args.dropout, attention_dropout=args.dropout)
-    model = EMDR2Model(retr, cfg, V_T5, V_BERT, K, S, S_ret, cls_id=101, sep_id=102, checkpoint_activations=True)
+    model = EMDR2Model(retr, cfg, V_T5, V_BERT, K, S, S_ret, cls_id=101, sep_id=102, checkpoint_activations=(micro == 1))
     model.train()
     # flat buckets: masters / gradients / moments / bf16 working copies back to back; ~20 optimizer launches per step; with world > 1 the
     # buckets are all-reduced in bf16 (0.88 GB on the wire) as their last gradient arrives from the backward
@@ -130,7 +139,7 @@ def setup(args, rank, world, index=None, topk=50):
 
     from emdr2_amd.training import RetentionGuard
     # the retention plan in force (run() fills it in) and the all-ranks-together recovery from a step that runs out of HBM
-    guard = RetentionGuard(model, opt, forward_progress=lambda: retr.searches)
+    guard = RetentionGuard(model, opt, forward_progress=lambda: retr.searches, micro=micro, batch=B)
     plan = guard.plan
 
     def step():
@@ -145,17 +154,25 @@ def setup(args, rank, world, index=None, topk=50):
             indexer.pump()                                                # side stream: overlaps with the training kernels below
         bt = make_batch()
         opt.zero_grad()
-        lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
-        loss, stats = emdr2_loss(lm, tlp, one, bt["labels"], bt["mask"], eos_id=30523)
-        if inject == (rank, calls[0]):
-            raise torch.cuda.OutOfMemoryError("injected by EMDR2_BENCH_INJECT_OOM (tests/test_dist_gpu.py)")
-        loss.backward()
+
+        def injected(group=0):
+            if inject == (rank, calls[0]) and group == 0:
+                raise torch.cuda.OutOfMemoryError("injected by EMDR2_BENCH_INJECT_OOM (tests/test_dist_gpu.py)")
+        if guard.micro > 1:
+            # the batch's questions in groups: one search, then forward + backward per group, every activation kept (zero recompute)
+            loss, stats = model.forward_backward(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"], bt["labels"], bt["mask"],
+                                                 30523, micro_batches=guard.micro, on_group=injected)
+        else:
+            lm, tlp, one = model(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"])
+            loss, stats = emdr2_loss(lm, tlp, one, bt["labels"], bt["mask"], eos_id=30523)
+            injected()
+            loss.backward()
         opt.finish()                                                      # waits for the bucket all-reduces launched from inside the backward
         opt.step(lr=sched.get_lr())
         sched.step()
         return loss
 
-    return types.SimpleNamespace(make_batch=make_batch, retriever=retr, sched=sched, plan=plan, guard=guard, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
+    return types.SimpleNamespace(micro=micro, indexer=indexer, make_batch=make_batch, retriever=retr, sched=sched, plan=plan, guard=guard, keep_last_arg=getattr(args, "keep_last_layers", "auto"), selective_arg=getattr(args, "selective_layers", "auto"), keep_last=0, step=step, model=model, opt=opt, n_params=sum(p.numel() for p in model.parameters()), B=B, K=K, S=S, S_ret=S_ret,
                                  layers=args.layers, rows=args.rows, dropout=args.dropout, reindex=args.reindex_rows_per_step)
 
 
@@ -218,7 +235,8 @@ def run(ctx, steps, warmup, world):
     for _ in range(warmup):
         loss = ctx.step()
     fence()
-    keep, sel_r, sel_c = choose_retention(ctx, world)
+    # question micro-batches: every activation of a group is kept, nothing is re-run, there is no retention plan to choose
+    keep, sel_r, sel_c = choose_retention(ctx, world) if ctx.guard.micro == 1 else (0, 0, 0)
     full_ms = None
     if keep + sel_r + sel_c > 0:
         t0 = time.perf_counter()                             # for the record: one step with the reference's full per-layer recompute
@@ -321,7 +339,8 @@ def run(ctx, steps, warmup, world):
                    "tokens_real": (Kmod.PACKING.real_tokens // steps) if Kmod.PACKING.enabled else None,
                    "tokens_padded": (Kmod.PACKING.grid_tokens // steps) if Kmod.PACKING.enabled else
                                     ctx.B * ctx.S_ret + ctx.B * ctx.K * ctx.S_ret + 2 * ctx.B * ctx.K * ctx.S,
-                   "dropout": ctx.dropout, "activation_recompute": "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
+                   "question_micro_batches": ctx.guard.micro,
+                   "dropout": ctx.dropout, "activation_recompute": ("none: forward + backward in %d groups of %d questions, every activation of a group kept" % (ctx.guard.micro, ctx.B // ctx.guard.micro)) if ctx.guard.micro > 1 else "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
                                            ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
                                             "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),
                    "recompute_tflop_per_step": Kmod.RECOMPUTE.flops / steps / 1e12, "steps_rerun_after_out_of_memory": ctx.guard.reruns, "retention_thinned_after_out_of_memory": ctx.plan["thinned"],
@@ -346,6 +365,67 @@ def run(ctx, steps, warmup, world):
                      "padded_work_rate": {"tflops": fl_step * sps / 1e12, "frac_of_peak": fl_step * sps / 1e12 / MFMA_PEAK_TFLOPS,
                                           "flops_per_step_per_gpu": fl_step}},
     }
+
+
+def release():
+    """Drop what a finished `setup` / `run` left in module state (gradient sink, stashes) and give the cached HBM back."""
+    import gc
+    from emdr2_amd.model import kernels as Kmod
+    Kmod.GRAD_SINK = None
+    Kmod.ATTN_STASH.store.clear()
+    Kmod.FANIN.clear()
+    Kmod.PREMASK.clear()
+    gc.collect()
+    torch.cuda.empty_cache()
+
+
+def run_k100(args, rank, world, index=None, steps=2, topk=100, reload_interval=500):
+    """BASELINE configs[4] (TriviaQA shape: top-k 100 + continuous evidence re-embedding) at its PER-RANK shape: this rank's N/8-row index
+    shard (with `index` None -- the 1-GPU run -- a shard-sized index is built: ceil(rows / 8) rows), B questions per GPU in 8 question
+    micro-batches, the step timed twice: WITHOUT the refresher, then WITH `AsyncIndexBuilder` re-embedding N / (8 ranks x reload interval)
+    rows per step on its side stream into the spare index image (tasks/openqa/e2eqa/async_indexer.py:84-144, train_e2eqa.py:436-508,
+    megatron/indexer_emdr2.py:77-114).  SURVEY 8d: step-time inflation vs no refresh, refresh wall-time for the rank's rows."""
+    import copy
+    ranks = max(world, 8)
+    shard_rows = (args.rows + ranks - 1) // ranks if index is None else None
+    a = copy.copy(args)
+    a.micro_batches = getattr(args, "micro_batches_k100", 8)
+    pace = (args.rows + ranks * reload_interval - 1) // (ranks * reload_interval)
+    out = {}
+    if index is None:
+        a.rows = shard_rows
+        index = build_index(shard_rows, rank, world)
+    for label, rows_per_step in (("without_refresh", 0), ("with_refresh", pace)):
+        a.reindex_rows_per_step = rows_per_step
+        ctx = setup(a, rank, world, index=index, topk=topk)
+        res = run(ctx, steps, 1, world)
+        lo, hi = ctx.retriever.mips_index.local_rows()
+        out[label] = {"ms_per_step": res["ms_per_step"], "steps_per_s": res["steps_per_s"], "peak_hbm_gb": res["config"]["peak_hbm_gb"],
+                      "recompute_tflop_per_step": res["config"]["recompute_tflop_per_step"], "question_micro_batches": res["config"]["question_micro_batches"],
+                      "gemm_tflops": res["roofline"]["achieved"], "per_step": res["roofline"]["per_step"],
+                      "steps_rerun_after_out_of_memory": res["config"]["steps_rerun_after_out_of_memory"], "loss": res["config"]["loss"]}
+        if rows_per_step:
+            batches = (rows_per_step + 127) // 128
+            out[label]["rows_reembedded_per_step"] = batches * 128
+            out[label]["refresher_batches_done"] = int(ctx.indexer.iteration)
+        rank_rows = hi - lo
+        del ctx, res
+        release()
+    w, wo = out["with_refresh"]["ms_per_step"], out["without_refresh"]["ms_per_step"]
+    per_step = out["with_refresh"]["rows_reembedded_per_step"]
+    steps_per_pass = (rank_rows + per_step - 1) // per_step
+    out.update({
+        "workload": "BASELINE configs[4]: EMDR2 step, B=%d/GPU, top-k %d, S_ret %d, S %d, %d-row index shard per rank (N/%d of %d), refresher at "
+                    "N / (%d ranks x %d-step reload interval) = %d rows per step and rank" % (args.batch, topk, args.seq_ret, args.seq, rank_rows, ranks,
+                                                                                             args.rows, ranks, reload_interval, pace),
+        "n_gpus": world, "steps": steps, "ms_per_step": w, "steps_per_s": 1e3 / w,
+        "inflation_from_refresh": w / wo - 1.0,
+        "refresh_pass": {"rows_per_rank": rank_rows, "steps": steps_per_pass, "wall_s_at_this_pace": steps_per_pass * w / 1e3,
+                         "gpu_s_spent_on_it_per_rank": steps_per_pass * (w - wo) / 1e3,
+                         "note": "one pass re-embeds every row of the rank's shard once, spread over `steps` training steps; the swap is a pointer "
+                                 "exchange at a step boundary (the reference: a second set of GPUs + 32 GB of pickles reloaded every 500 steps)"},
+    })
+    return out
 
 
 def cpu_baseline_subprocess(seconds=12.0, limit=120.0, threads=0):

@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")     # tools/ may point this at lib/libemdr2_hip_exp.so (`make exp`) before first use
 
-EMDR2_ABI_VERSION = 2
+EMDR2_ABI_VERSION = 3
 FLAG_AMBIGUOUS = 1
 FLAG_OVERFLOW = 2
 MAX_TOPK = 120
@@ -34,6 +34,9 @@ SIGNATURES = {
     "emdr2_mips_exact_workspace_bytes_f32": (_i32, [_i64, _i32, ctypes.POINTER(_sz)]),
     "emdr2_mips_search_exact_f32": (_i32, [_vp, _i64, _i32, _i64, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "emdr2_mips_merge_f32": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "emdr2_mips_search_records": (_i32, [_vp, _i64, _i32, _i64, _vp, _vp, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "emdr2_mips_merge_records": (_i32, [_vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "emdr2_mips_pack_records": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "emdr2_mips_debug_scores": (_i32, [_vp, _i64, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "emdr2_mips_set_timing": (_i32, [_i32]),
     "emdr2_mips_timing_collect": (_i32, [ctypes.POINTER(ctypes.c_float), ctypes.POINTER(_i64), _i32, ctypes.POINTER(_i32)]),

@@ -35,6 +35,11 @@ def get_parser():
                         '[tokens, h] activation tensors and rebuild the rest (both LayerNorm outputs, the FFN pre-activation and GELU output) in '
                         'the backward, instead of being re-run whole (+6.3 GB per reader-encoder layer, +3.0 GB per context-tower layer at '
                         'batch 64 x top-k 50; packed row counts keep growing by 16,384-row steps over the first tens of steps: leave ~25 GB free)')
+    g.add_argument('--question-micro-batches', type=int, default=1,
+                   help='(not in the reference) run the forward / backward of a step over the batch in M groups of questions '
+                        '(EMDR2Model.forward_backward: one MIPS search for the whole batch, everything after it per group, gradients summed in '
+                        'the fp32 buckets, losses with batch-wide denominators).  M > 1 keeps every activation of a group instead of re-running '
+                        'layers in the backward: --checkpoint-activations is then ignored (batch 64 x top-k 50: M = 4, top-k 100: M = 8)')
     g.add_argument('--seed', type=int, default=1234)
     g.add_argument('--init-method-std', type=float, default=0.02)
     g.add_argument('--lr', type=float, default=None)

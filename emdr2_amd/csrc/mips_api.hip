@@ -132,9 +132,11 @@ static const int kBN[3] = {512, 256, 128};
 static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq,
                        const void *queries, int n_q, int k, const int32_t *ids, void *out_dist, int32_t *out_idx,
                        int64_t *out_row, uint32_t *out_flags, void *workspace, size_t workspace_bytes,
-                       emdr2_stream_t stream_, int f32)
+                       emdr2_stream_t stream_, int f32, uint4 *out_rec = nullptr)
 {
-    if (!tiled || !emax_sq || !queries || !out_dist || !out_idx || !out_row || !out_flags || !workspace) return EMDR2_E_BADARG;
+    if (!tiled || !emax_sq || !queries || !out_flags || !workspace) return EMDR2_E_BADARG;
+    if (!out_rec && (!out_dist || !out_idx || !out_row)) return EMDR2_E_BADARG;
+    if (out_rec && ((uintptr_t)out_rec & 15)) return EMDR2_E_BADARG;
     if (n_q < 1 || k < 1 || k > EMDR2_MAX_TOPK || bad_shape(n_rows, dim) || n_rows < 1) return EMDR2_E_BADARG;
     Workspace w;
     if (carve((char *)workspace, dim, &w) > workspace_bytes) return EMDR2_E_WORKSPACE;
@@ -254,10 +256,11 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         fp.qnorm = w.qnorm;
         fp.emax_sq = emax_sq;
         fp.ids = ids;
-        fp.out_dist = f32 ? (void *)((float *)out_dist + (size_t)q0 * k) : (void *)((uint16_t *)out_dist + (size_t)q0 * k);
+        fp.out_rec = out_rec ? out_rec + (size_t)q0 * k : nullptr;
+        fp.out_dist = out_rec ? nullptr : (f32 ? (void *)((float *)out_dist + (size_t)q0 * k) : (void *)((uint16_t *)out_dist + (size_t)q0 * k));
         fp.f32 = f32;
-        fp.out_idx = out_idx + (size_t)q0 * k;
-        fp.out_row = out_row + (size_t)q0 * k;
+        fp.out_idx = out_rec ? nullptr : out_idx + (size_t)q0 * k;
+        fp.out_row = out_rec ? nullptr : out_row + (size_t)q0 * k;
         fp.flags = out_flags + q0;
         fp.n_rows = n_rows;
         fp.row_base = row_base;
@@ -287,6 +290,29 @@ int emdr2_mips_search_f32(const void *tiled, int64_t n_rows, int dim, int64_t ro
 {
     return search_impl(tiled, n_rows, dim, row_base, emax_sq, queries, n_q, k, ids, out_dist, out_idx, out_row, out_flags, workspace,
                        workspace_bytes, stream, 1);
+}
+
+int emdr2_mips_search_records(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq, const void *queries, int n_q,
+                              int k, const int32_t *ids, int f32, void *out_records, uint32_t *out_flags, void *workspace,
+                              size_t workspace_bytes, emdr2_stream_t stream)
+{
+    if (!out_records) return EMDR2_E_BADARG;
+    return search_impl(tiled, n_rows, dim, row_base, emax_sq, queries, n_q, k, ids, nullptr, nullptr, nullptr, out_flags, workspace,
+                       workspace_bytes, stream, f32 ? 1 : 0, (uint4 *)out_records);
+}
+
+int emdr2_mips_merge_records(const void *records_in, int n_shards, int n_q, int k, int f32, void *out_dist, int32_t *out_idx, int64_t *out_row,
+                             emdr2_stream_t stream)
+{
+    if (!records_in || ((uintptr_t)records_in & 15) || !out_dist || !out_idx || !out_row || n_shards < 1 || n_q < 1 || k < 1) return EMDR2_E_BADARG;
+    return mips_launch_merge_records((const uint4 *)records_in, n_shards, n_q, k, f32 ? 1 : 0, out_dist, out_idx, out_row, (hipStream_t)stream);
+}
+
+int emdr2_mips_pack_records(const void *dist, const int32_t *idx, const int64_t *row, const int32_t *sel, int n_sel, int k, int f32,
+                            void *records, emdr2_stream_t stream)
+{
+    if (!dist || !idx || !row || !sel || !records || ((uintptr_t)records & 15) || n_sel < 0 || k < 1) return EMDR2_E_BADARG;
+    return mips_launch_pack_records(dist, idx, row, sel, n_sel, k, f32 ? 1 : 0, (uint4 *)records, (hipStream_t)stream);
 }
 
 int emdr2_mips_exact_workspace_bytes_f32(int64_t n_rows, int n_sel, size_t *bytes)

@@ -367,15 +367,23 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
         if (rank < kk) {
             const uint32_t row = 0xffffffffu - (uint32_t)mine;
             const size_t o = (size_t)q * p.k + rank;
-            if (p.f32) ((float *)p.out_dist)[o] = f32_unorder((uint32_t)(mine >> 32));
-            else ((uint16_t *)p.out_dist)[o] = h16_unorder((uint32_t)(mine >> 32));
-            p.out_row[o] = p.row_base + (int64_t)row;
-            p.out_idx[o] = p.ids ? p.ids[row] : (int32_t)(p.row_base + (int64_t)row);
+            const int64_t grow = p.row_base + (int64_t)row;
+            const int32_t gid = p.ids ? p.ids[row] : (int32_t)grow;
+            if (p.out_rec) {
+                const uint32_t bits = p.f32 ? __float_as_uint(f32_unorder((uint32_t)(mine >> 32))) : (uint32_t)h16_unorder((uint32_t)(mine >> 32));
+                p.out_rec[o] = make_uint4((uint32_t)grow, (uint32_t)((uint64_t)grow >> 32), (uint32_t)gid, bits);
+            } else {
+                if (p.f32) ((float *)p.out_dist)[o] = f32_unorder((uint32_t)(mine >> 32));
+                else ((uint16_t *)p.out_dist)[o] = h16_unorder((uint32_t)(mine >> 32));
+                p.out_row[o] = grow;
+                p.out_idx[o] = gid;
+            }
             if (rank == kk - 1) sh_kth = (uint32_t)(mine >> 32);
         }
     }
     for (unsigned j = kk + tid; j < (unsigned)p.k; j += 256) { // shard holds fewer than k rows
         const size_t o = (size_t)q * p.k + j;
+        if (p.out_rec) { p.out_rec[o] = make_uint4(0xffffffffu, 0xffffffffu, 0xffffffffu, p.f32 ? 0xff800000u : 0xfc00u); continue; }
         if (p.f32) ((float *)p.out_dist)[o] = -INFINITY; else ((uint16_t *)p.out_dist)[o] = 0xfc00;
         p.out_row[o] = -1; p.out_idx[o] = -1;
     }
@@ -499,6 +507,82 @@ int mips_launch_merge_f32(const float *dist_in, const int32_t *idx_in, const int
 {
     if (n_shards * k > MERGE_MAX) return -4;
     hipLaunchKernelGGL(merge_f32_kernel, dim3(n_q), dim3(256), 0, stream, dist_in, idx_in, row_in, n_shards, n_q, k, out_dist, out_idx, out_row);
+    return CHECK_LAUNCH();
+}
+
+// the merge over gathered 16-byte records [n_shards, n_q, k] (FinalizeParams::out_rec): what a sharded search exchanges in its ONE
+// all-gather is the finalize kernel's own output, and this kernel reads the gathered buffer as it arrives -- no casts / stacks between.
+// Same keys, same order, same outputs as merge_kernel / merge_f32_kernel.
+template <bool F32>
+__global__ void __launch_bounds__(256) merge_records_kernel(const uint4 *rec_in, int n_shards, int n_q, int k, void *out_dist, int32_t *out_idx,
+                                                            int64_t *out_row)
+{
+    __shared__ uint64_t key[MERGE_MAX];
+    __shared__ unsigned nvalid;
+    const int q = blockIdx.x, tid = threadIdx.x;
+    const int n = n_shards * k;
+    if (tid == 0) nvalid = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int s = i / k, j = i - s * k;
+        const uint4 r = rec_in[((size_t)s * n_q + q) * k + j];
+        const int64_t row = (int64_t)(((uint64_t)r.y << 32) | r.x);
+        uint64_t kv = 0;
+        if (row >= 0) {
+            kv = F32 ? (((uint64_t)f32_order(__uint_as_float(r.w)) << 32) | (uint64_t)(0xffffffffu - (uint32_t)row))
+                     : (((uint64_t)h16_order((uint16_t)r.w) << 48) | (0xffffffffffffull - (uint64_t)row));
+            atomicAdd(&nvalid, 1u);
+        }
+        key[i] = kv;
+    }
+    __syncthreads();
+    const unsigned nv = nvalid;
+    for (int i = tid; i < n; i += 256) {
+        const uint64_t mine = key[i];
+        if (mine == 0) continue;
+        unsigned rank = 0;
+        for (int t = 0; t < n; ++t) rank += (key[t] > mine);
+        if (rank < (unsigned)k) {
+            const int s = i / k, j = i - s * k;
+            const uint4 r = rec_in[((size_t)s * n_q + q) * k + j];
+            const size_t o = (size_t)q * k + rank;
+            if (F32) ((float *)out_dist)[o] = __uint_as_float(r.w); else ((uint16_t *)out_dist)[o] = (uint16_t)r.w;
+            out_idx[o] = (int32_t)r.z; out_row[o] = (int64_t)(((uint64_t)r.y << 32) | r.x);
+        }
+    }
+    for (unsigned j = nv + tid; j < (unsigned)k; j += 256) {
+        const size_t o = (size_t)q * k + j;
+        if (F32) ((float *)out_dist)[o] = -INFINITY; else ((uint16_t *)out_dist)[o] = 0xfc00;
+        out_idx[o] = -1; out_row[o] = -1;
+    }
+}
+
+int mips_launch_merge_records(const uint4 *rec_in, int n_shards, int n_q, int k, int f32, void *out_dist, int32_t *out_idx, int64_t *out_row,
+                              hipStream_t stream)
+{
+    if (n_shards * k > MERGE_MAX) return -4;
+    if (f32) hipLaunchKernelGGL(merge_records_kernel<true>, dim3(n_q), dim3(256), 0, stream, rec_in, n_shards, n_q, k, out_dist, out_idx, out_row);
+    else hipLaunchKernelGGL(merge_records_kernel<false>, dim3(n_q), dim3(256), 0, stream, rec_in, n_shards, n_q, k, out_dist, out_idx, out_row);
+    return CHECK_LAUNCH();
+}
+
+__global__ void __launch_bounds__(128) pack_records_kernel(const void *dist, const int32_t *idx, const int64_t *row, const int32_t *sel, int k,
+                                                           int f32, uint4 *rec)
+{
+    const int q = sel[blockIdx.x];
+    for (int j = threadIdx.x; j < k; j += 128) {
+        const size_t o = (size_t)q * k + j;
+        const int64_t r = row[o];
+        const uint32_t bits = f32 ? __float_as_uint(((const float *)dist)[o]) : (uint32_t)((const uint16_t *)dist)[o];
+        rec[o] = make_uint4((uint32_t)r, (uint32_t)((uint64_t)r >> 32), (uint32_t)idx[o], bits);
+    }
+}
+
+int mips_launch_pack_records(const void *dist, const int32_t *idx, const int64_t *row, const int32_t *sel, int n_sel, int k, int f32, uint4 *rec,
+                             hipStream_t stream)
+{
+    if (n_sel < 1) return 0;
+    hipLaunchKernelGGL(pack_records_kernel, dim3(n_sel), dim3(128), 0, stream, dist, idx, row, sel, k, f32, rec);
     return CHECK_LAUNCH();
 }
 

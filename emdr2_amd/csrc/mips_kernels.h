@@ -73,10 +73,18 @@ struct FinalizeParams {
     int dim, n_q, k, kp;
     unsigned capq;
     int f32;                 // 1: FaissMIPSIndex-style scores RNE_fp32(exact dot), order (fp32 score desc, row asc)
+    uint4 *out_rec;          // non-null: ONE 16-byte record per (query, slot) instead of the three arrays -- {row lo, row hi, idx, score bits
+                             // (fp16 in the low half, or fp32)} -- written straight into the all-gather send buffer of a sharded search
 };
 int mips_launch_finalize(const FinalizeParams &p, bool select_first, hipStream_t stream);      // select_first: run the select of the last scan segment in the same launch
 int mips_launch_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
                           float *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
+// the same merges over gathered 16-byte records [n_shards, n_q, k] (FinalizeParams::out_rec)
+int mips_launch_merge_records(const uint4 *rec_in, int n_shards, int n_q, int k, int f32, void *out_dist, int32_t *out_idx, int64_t *out_row,
+                              hipStream_t stream);
+// (dist, idx, row) rows sel[i] -> records rows sel[i] (queries re-done by the all-exact path)
+int mips_launch_pack_records(const void *dist, const int32_t *idx, const int64_t *row, const int32_t *sel, int n_sel, int k, int f32, uint4 *rec,
+                             hipStream_t stream);
 int mips_launch_merge(const uint16_t *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q,
                       int k, uint16_t *out_dist, int32_t *out_idx, int64_t *out_row, hipStream_t stream);
 

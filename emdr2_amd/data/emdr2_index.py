@@ -284,6 +284,57 @@ class HipIndexShard(object):
                 self.search_exact(q, sel, k, dist, idx, row, flags)
         return dist, idx, row, flags
 
+    def search_records(self, queries, k, f32=False, out=None, exact_fallback=True):
+        """The shard's canonical top-k as ONE uint8 [Q, k, 16] tensor of packed records {int64 global row | int32 doc id | score bits}
+        (include/emdr2_mips.h) -- what a sharded search puts into its all-gather: `out` may be the send buffer itself.  Queries the fast
+        path flags are re-done by the all-exact path and their records overwritten (one host sync, as in `search`).  -> (records, flags)."""
+        if self._filled != self.n_rows:
+            raise RuntimeError("shard not fully populated (%d of %d rows)" % (self._filled, self.n_rows))
+        if queries.dtype != torch.float16 or queries.dim() != 2 or queries.shape[1] != self.dim or not queries.is_cuda:
+            raise ValueError("queries must be a CUDA float16 [Q, %d] tensor" % self.dim)
+        if not (1 <= k <= _native.MAX_TOPK):
+            raise ValueError("top_k must be in [1, %d]" % _native.MAX_TOPK)
+        q = queries.contiguous()
+        nq = q.shape[0]
+        rec = out if out is not None else torch.empty((nq, k, 16), dtype=torch.uint8, device=self.device)
+        if rec.shape != (nq, k, 16) or rec.dtype != torch.uint8 or not rec.is_contiguous():
+            raise ValueError("records buffer must be a contiguous uint8 [Q, k, 16] tensor")
+        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        if self.n_rows == 0:
+            rec.view(torch.int32).copy_(torch.tensor([-1, -1, -1, 0xff800000 - (1 << 32) if f32 else 0xfc00], dtype=torch.int32, device=self.device))
+            return rec, flags
+        ws = self._workspace(k)
+        ids_ptr = self.ids.data_ptr() if self.ids is not None else None
+        _native.check(self.lib.emdr2_mips_search_records(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base, self.emax_sq.data_ptr(),
+                                                         q.data_ptr(), nq, k, ids_ptr, int(bool(f32)), rec.data_ptr(), flags.data_ptr(),
+                                                         ws.data_ptr(), ws.numel(), _native.stream_ptr()), "mips_search_records")
+        if exact_fallback:
+            sel = torch.nonzero(flags).to(torch.int32).flatten()     # one host sync, like the reference's .item() loop
+            if sel.numel():
+                sel = sel.contiguous()
+                dist = torch.empty((nq, k), dtype=torch.float32 if f32 else torch.float16, device=self.device)
+                idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
+                row = torch.empty((nq, k), dtype=torch.int64, device=self.device)
+                if f32:
+                    self._search_exact_f32(q, sel, k, dist, idx, row, flags)
+                else:
+                    self.search_exact(q, sel, k, dist, idx, row, flags)
+                _native.check(self.lib.emdr2_mips_pack_records(dist.data_ptr(), idx.data_ptr(), row.data_ptr(), sel.data_ptr(), int(sel.numel()), k,
+                                                               int(bool(f32)), rec.data_ptr(), _native.stream_ptr()), "mips_pack_records")
+        return rec, flags
+
+    def _search_exact_f32(self, q, sel, k, dist, idx, row, flags):
+        import ctypes
+        nbytes = ctypes.c_size_t()
+        _native.check(self.lib.emdr2_mips_exact_workspace_bytes_f32(self.n_rows, int(sel.numel()), ctypes.byref(nbytes)), "exact_ws_f32")
+        if self._xws is None or self._xws.numel() < nbytes.value:
+            self._xws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
+        ids_ptr = self.ids.data_ptr() if self.ids is not None else None
+        _native.check(self.lib.emdr2_mips_search_exact_f32(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base, q.data_ptr(), q.shape[0],
+                                                           sel.data_ptr(), int(sel.numel()), k, ids_ptr, dist.data_ptr(), idx.data_ptr(),
+                                                           row.data_ptr(), flags.data_ptr(), self._xws.data_ptr(), self._xws.numel(),
+                                                           _native.stream_ptr()), "mips_search_exact_f32")
+
     def search_f32(self, queries, k, exact_fallback=True):
         """FaissMIPSIndex-style scores: queries fp16 [Q, dim] -> (dist fp32 [Q,k] = RNE_fp32(exact dot), idx int32, row int64, flags),
         order (fp32 score desc, row asc)."""
@@ -311,15 +362,7 @@ class HipIndexShard(object):
         if exact_fallback:
             sel = torch.nonzero(flags).to(torch.int32).flatten()
             if sel.numel():
-                nbytes = ctypes.c_size_t()
-                _native.check(self.lib.emdr2_mips_exact_workspace_bytes_f32(self.n_rows, int(sel.numel()), ctypes.byref(nbytes)), "exact_ws_f32")
-                if self._xws is None or self._xws.numel() < nbytes.value:
-                    self._xws = torch.empty(nbytes.value, dtype=torch.uint8, device=self.device)
-                sel = sel.contiguous()
-                _native.check(self.lib.emdr2_mips_search_exact_f32(self.tiled.data_ptr(), self.n_rows, self.dim, self.row_base, q.data_ptr(), nq,
-                                                                   sel.data_ptr(), int(sel.numel()), k, ids_ptr, dist.data_ptr(), idx.data_ptr(),
-                                                                   row.data_ptr(), flags.data_ptr(), self._xws.data_ptr(), self._xws.numel(),
-                                                                   _native.stream_ptr()), "mips_search_exact_f32")
+                self._search_exact_f32(q, sel.contiguous(), k, dist, idx, row, flags)
         return dist, idx, row, flags
 
     def search_exact(self, q, sel, k, dist, idx, row, flags):
@@ -361,6 +404,21 @@ def merge_shard_results(dist, idx, row):
     orow = torch.empty((nq, k), dtype=torch.int64, device=dist.device)
     _native.check(lib.emdr2_mips_merge(dist.contiguous().data_ptr(), idx.contiguous().data_ptr(), row.contiguous().data_ptr(),
                                        s, nq, k, od.data_ptr(), oi.data_ptr(), orow.data_ptr(), _native.stream_ptr()), "mips_merge")
+    return od, oi, orow
+
+
+def merge_shard_records(records, f32=False):
+    """Gathered records uint8 [S, Q, k, 16] (HipIndexShard.search_records of every shard, as the all-gather delivered them) -> merged
+    (dist [Q, k], idx int32, row int64): ONE launch, no casts in between."""
+    lib = _native.lib()
+    s, nq, k, _ = records.shape
+    if records.dtype != torch.uint8 or records.shape[3] != 16 or not records.is_contiguous():
+        raise ValueError("records must be a contiguous uint8 [S, Q, k, 16] tensor")
+    od = torch.empty((nq, k), dtype=torch.float32 if f32 else torch.float16, device=records.device)
+    oi = torch.empty((nq, k), dtype=torch.int32, device=records.device)
+    orow = torch.empty((nq, k), dtype=torch.int64, device=records.device)
+    _native.check(lib.emdr2_mips_merge_records(records.data_ptr(), s, nq, k, int(bool(f32)), od.data_ptr(), oi.data_ptr(), orow.data_ptr(),
+                                               _native.stream_ptr()), "mips_merge_records")
     return od, oi, orow
 
 
@@ -472,22 +530,44 @@ class DistributedBruteForceIndex(object):
         q = query_embeds
         if q.dtype != torch.float16:
             q = q.to(torch.float16)   # reference queries are fp16 under FP16_Module; bf16/fp32 are rounded once
-        dist, idx, row, _ = self.shard.search(q.contiguous(), top_k)
         rank, world = self._world()
-        if world > 1:
-            dist, idx, row = self._exchange_and_merge(dist, idx, row, world)
+        if world == 1:
+            dist, idx, _, _ = self.shard.search(q.contiguous(), top_k)
+            return dist, idx
+        dist, idx, _ = self._search_exchange_merge(q.contiguous(), top_k, rank, world, f32=False)
         return dist, idx
 
-    def _exchange_and_merge(self, dist, idx, row, world):
-        nq, k = dist.shape
-        packed = torch.stack([dist.view(torch.int16).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
-        gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)  # concatenated along dim 0
-        torch.distributed.all_gather_into_tensor(gathered, packed, group=self.process_group)
-        gathered = gathered.view(world, 3, nq, k)
-        g_dist = gathered[:, 0].to(torch.int16).view(torch.float16).contiguous()
-        g_idx = gathered[:, 1].to(torch.int32).contiguous()
-        g_row = gathered[:, 2].contiguous()
-        return self._merge(g_dist, g_idx, g_row)
+    def _search_exchange_merge(self, q, top_k, rank, world, f32):
+        """Sharded search: the shard scan's last kernel writes its packed records straight into this rank's slice of the gather buffer, ONE
+        all-gather (16 bytes per (query, slot) and rank: 410 KB at 512 x 50), ONE merge launch on the gathered buffer.  Nothing else runs
+        between them; `exchange_events` (when a list) receives a (start, end) event pair around all-gather + merge."""
+        nq = q.shape[0]
+        gathered = torch.empty((world, nq, top_k, 16), dtype=torch.uint8, device=q.device)
+        self.shard.search_records(q, top_k, f32=f32, out=gathered[rank])
+        ev = getattr(self, "exchange_events", None)
+        if ev is not None and len(ev) < 4096:
+            pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            pair[0].record()
+        else:
+            pair = None
+        self._all_gather_records(gathered, rank)
+        out = self._merge_records(gathered, f32)
+        if pair is not None:
+            pair[1].record()
+            ev.append(pair)
+        return out
+
+    def _all_gather_records(self, gathered, rank):
+        # RCCL: in place -- this rank's slice of `gathered` (which its finalize kernel has just written) IS its send buffer (the in-place
+        # form of ncclAllGather: sendbuff == recvbuff + rank * count).  Other transports (gloo in the dry runs) get a private copy.
+        mine = gathered[rank]
+        if torch.distributed.get_backend(self.process_group) != "nccl":
+            mine = mine.clone()
+        # (output = the ranks' inputs concatenated along dim 0: gloo checks the shapes, RCCL only the element count)
+        torch.distributed.all_gather_into_tensor(gathered.view((-1,) + tuple(gathered.shape[2:])), mine, group=self.process_group)
+
+    def _merge_records(self, gathered, f32):
+        return merge_shard_records(gathered, f32)
 
 
 class FaissMIPSIndex(DistributedBruteForceIndex):
@@ -512,16 +592,11 @@ class FaissMIPSIndex(DistributedBruteForceIndex):
             raise RuntimeError("MIPS Index is not initialized")
         q = torch.as_tensor(query_embeds)
         q = q.to(device=self.shard.device, dtype=torch.float16).contiguous()
-        dist, idx, row, _ = self.shard.search_f32(q, top_k)
         rank, world = self._world()
         if world > 1:
-            nq, k = dist.shape
-            packed = torch.stack([dist.view(torch.int32).to(torch.int64), idx.to(torch.int64), row], dim=0).contiguous()
-            gathered = torch.empty((world * 3, nq, k), dtype=torch.int64, device=packed.device)
-            torch.distributed.all_gather_into_tensor(gathered, packed, group=self.process_group)
-            gathered = gathered.view(world, 3, nq, k)
-            dist, idx, row = self._merge_f32(gathered[:, 0].to(torch.int32).view(torch.float32).contiguous(),
-                                             gathered[:, 1].to(torch.int32).contiguous(), gathered[:, 2].contiguous())
+            dist, idx, row = self._search_exchange_merge(q, top_k, rank, world, f32=True)
+        else:
+            dist, idx, row, _ = self.shard.search_f32(q, top_k)
         distances = dist.cpu().numpy()
         indices = idx.to(torch.int64).cpu().numpy()
         if not reconstruct:

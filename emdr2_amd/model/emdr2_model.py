@@ -246,6 +246,61 @@ class EMDR2Model(torch.nn.Module):
             return lm_logits, topk_log_probs, enc, qext.reshape(B, Kk * S)
         return lm_logits, topk_log_probs, one
 
+    def forward_backward(self, query_uid, query_ids_bert, query_types, query_mask_bert, query_ids_t5, query_ids_t5_len, dec_ids, labels,
+                         loss_mask, eos_id, micro_batches=1, ret_kldiv=False, on_group=None):
+        """Forward, EMDR2 loss AND backward of one training step with the B questions of the batch run in `micro_batches` groups; returns
+        (loss, stats) of the whole batch, gradients delivered (the reference's step is `model(...)` -> `get_loss_and_retriever_utility` ->
+        `backward_step` over the undivided batch: emdr2_model.py:87-214, train_e2eqa.py:126-181, megatron/training.py:165-200).
+
+        Why it is the same step: only the query tower and the MIPS search see the batch as a whole (ONE search per step: its cost is the
+        index scan, not the number of queries) -- they run once, for all B questions.  Everything after the search is per question: a
+        question's K passages go through the context tower, the prior is a softmax over ITS K scores (:134-145), FiD cross-attention
+        concatenates ITS K passages (:159-161), both losses are sums over questions divided by batch-wide token counts (`loss_totals`).
+        So each group's loss is taken with the whole batch's denominators and back-propagated at once; parameter gradients add up in the
+        optimizer's flat fp32 buckets (training.FlatAdam counts m contributions per parameter and releases a bucket to its all-reduce when
+        the last one has arrived), the query embeddings' gradient is collected per group and sent through the query tower once at the end.
+        What it buys: the activations alive at any time are those of B / m questions, so NO layer has to be re-run in the backward
+        (--checkpoint-activations off: zero recompute) inside 288 GB even at top-k 100.  Dropout: group i draws its masks from seeds
+        hashed with i (kernels.DROPOUT.micro), so an undivided step (m = 1) is bit-identical to `forward` + `emdr2_loss` + `backward`.
+        `on_group(i)`: called between group i's forward and its backward (test hook: injected allocation failures)."""
+        B = query_ids_bert.shape[0]
+        m = int(micro_batches)
+        if m < 1 or B % m:
+            raise ValueError("micro_batches must divide the batch (%d questions, %d groups)" % (B, m))
+        if not self.training:
+            raise ValueError("forward_backward is a training-mode call")
+        totals = loss_totals(labels, loss_mask, eos_id)
+        query_logits = self.retriever_embedder(query_ids_bert, None, query_types, "query", self.disable_retriever_dropout)
+        if self.no_query_embedder_training:
+            query_logits = query_logits.detach()
+        with torch.no_grad():                                            # ONE search + device-side fetch / assembly for all B questions
+            ctx_ids, ctx_types, qext, qone, _, _ = self.evidence_retriever.get_topk_assembled(
+                query_logits.detach(), query_uid, query_ids_t5, query_ids_t5_len, self.cls_id, self.sep_id, self.pad_id)
+        Kk = ctx_ids.shape[1]
+        q_leaf = query_logits.detach().requires_grad_(query_logits.requires_grad)
+        g = B // m
+        loss_sum, stats_sum = None, {}
+        try:
+            for i in range(m):
+                K.DROPOUT.micro = i
+                lo, hi = i * g, (i + 1) * g
+                lm, tlp, one = self.forward_assembled(q_leaf[lo:hi], ctx_ids[lo:hi], ctx_types[lo:hi], qext[lo * Kk:hi * Kk], qone[lo * Kk:hi * Kk],
+                                                      dec_ids[lo:hi])
+                loss, stats = emdr2_loss(lm, tlp, one, labels[lo:hi], loss_mask[lo:hi], eos_id, ret_kldiv=ret_kldiv, totals=totals)
+                del lm, tlp, one
+                if on_group is not None:
+                    on_group(i)
+                loss.backward()                                          # frees this group's activations before the next group's forward
+                loss_sum = loss.detach() if loss_sum is None else loss_sum + loss.detach()
+                for k_, v in stats.items():
+                    stats_sum[k_] = v if k_ not in stats_sum else stats_sum[k_] + v
+                del loss, stats
+        finally:
+            K.DROPOUT.micro = 0
+        if q_leaf.grad is not None:
+            query_logits.backward(q_leaf.grad)                           # the query tower's backward: once, over all B questions
+        return loss_sum, stats_sum
+
     def state_dict_for_save_checkpoint(self):
         """The reference's nested checkpoint dict (emdr2_model.py:217-226; layout in emdr2_amd/checkpointing.py)."""
         from emdr2_amd import checkpointing
@@ -291,12 +346,23 @@ class EMDR2Model(torch.nn.Module):
         checkpointing.load_dualencoder_checkpoint(self.retriever_model, pretrained_dpr_load)
 
 
-def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id, ret_kldiv=False):
-    """_cross_entropy_forward_step + get_loss_and_retriever_utility (tasks/openqa/e2eqa/train_e2eqa.py:72-181).
-    The two vocabulary-sized log-softmax + gather passes run in the HIP kernel; what is left in torch acts on [B,L] / [B,K,L]."""
+def loss_totals(labels, loss_mask, eos_id):
+    """The three batch-wide denominators of `emdr2_loss` (device scalars): sum of the loss mask, sum of the utility mask (answer tokens
+    before [EOS], train_e2eqa.py:113-118), batch size.  A micro-batch's losses divided by THESE add up to the full batch's."""
     mask = loss_mask.float()
+    lab = labels.masked_fill(~loss_mask.to(torch.bool), 0)
+    return mask.sum(), mask.masked_fill(lab >= eos_id, 0).sum(), labels.shape[0]
+
+
+def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id, ret_kldiv=False, totals=None):
+    """_cross_entropy_forward_step + get_loss_and_retriever_utility (tasks/openqa/e2eqa/train_e2eqa.py:72-181).
+    The two vocabulary-sized log-softmax + gather passes run in the HIP kernel; what is left in torch acts on [B,L] / [B,K,L].
+    `totals` (from `loss_totals` of the whole batch): the arguments are a group of the batch's questions and every mean is taken with the
+    whole batch's denominator, so losses, statistics and gradients of the groups SUM to those of the undivided batch."""
+    mask = loss_mask.float()
+    mask_sum, util_sum, batch = totals if totals is not None else (mask.sum(), None, labels.shape[0])
     gold = K.lse_gather(lm_logits, labels)                                                    # [B, L] fp32
-    lm_loss = -torch.sum(gold * mask * (labels != 0)) / mask.sum()                            # CrossEntropyLoss(ignore_index=0) * loss_mask
+    lm_loss = -torch.sum(gold * mask * (labels != 0)) / mask_sum                              # CrossEntropyLoss(ignore_index=0) * loss_mask
     stats = {"lm_loss": lm_loss.detach()}
     retriever_loss = torch.zeros((), device=lm_logits.device)
     if lm_logits_one_context is not None:
@@ -309,13 +375,13 @@ def emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_ma
             gold1 = K.lse_gather(lm_logits_one_context, labk).detach()
         if ret_kldiv:                                                                         # --ret-kldiv (train_e2eqa.py:184-214)
             teacher_log = torch.sum(gold1 * mask.unsqueeze(1), dim=2) / torch.sum(mask.unsqueeze(1), dim=2)
-            retriever_loss = torch.nn.functional.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='batchmean')
+            retriever_loss = torch.nn.functional.kl_div(topk_log_probs.float(), torch.softmax(teacher_log, dim=1), reduction='sum') / batch   # 'batchmean'
             stats["retriever_loss"] = retriever_loss.detach()
             return lm_loss + retriever_loss, stats
         marginal = K.marginal_logsumexp(topk_log_probs, gold1)                                  # [B, L] = logsumexp_k(prior + gold), HIP kernel pair
-        retriever_loss = -torch.sum(marginal * mask) / mask.sum()
+        retriever_loss = -torch.sum(marginal * mask) / mask_sum
         util_mask = mask.masked_fill(lab >= eos_id, 0)
-        stats["retriever_utility"] = (torch.sum((marginal - gold1[:, -1, :]) * util_mask) / util_mask.sum()).detach()
-        stats["null_block_lm_loss"] = (-torch.sum(gold1[:, -1, :] * mask) / mask.sum()).detach()
+        stats["retriever_utility"] = (torch.sum((marginal - gold1[:, -1, :]) * util_mask) / (util_mask.sum() if util_sum is None else util_sum)).detach()
+        stats["null_block_lm_loss"] = (-torch.sum(gold1[:, -1, :] * mask) / mask_sum).detach()
     stats["retriever_loss"] = retriever_loss.detach()
     return lm_loss + retriever_loss, stats

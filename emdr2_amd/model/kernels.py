@@ -34,17 +34,19 @@ class _DropoutState(object):
     (base seed, optimizer step, pass id, site id).  It is a pure function of those four, so a layer recomputed by
     --checkpoint-activations regenerates exactly the bits of its first forward, and a backward regenerates the forward's mask instead of
     storing it.  `pass_id` separates the several forward passes one training step makes through the same layers (reader over K documents
-    vs. the one-context pass).  Like the reference (megatron/initialize.py:_set_random_seed) all data-parallel ranks use the same seed."""
+    vs. the one-context pass); `micro` the question micro-batches of one step (EMDR2Model.forward_backward: every group of questions runs
+    through the same sites with rows numbered from 0, so without it all groups would share one mask per site; micro 0 = the seeds of an
+    undivided step).  Like the reference (megatron/initialize.py:_set_random_seed) all data-parallel ranks use the same seed."""
 
     def __init__(self):
-        self.base_seed, self.step, self.pass_id, self._sites = 1234, 0, 0, 0
+        self.base_seed, self.step, self.pass_id, self.micro, self._sites = 1234, 0, 0, 0, 0
 
     def new_site(self):
         self._sites += 1
         return self._sites
 
     def seed(self, site):
-        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77 + self.pass_id * 0xC2B2AE3D + site * 0x27D4EB2F) & 0xFFFFFFFF
+        x = (self.base_seed * 0x9E3779B1 + self.step * 0x85EBCA77 + self.pass_id * 0xC2B2AE3D + site * 0x27D4EB2F + self.micro * 0x165667B1) & 0xFFFFFFFF
         x ^= x >> 16; x = (x * 0x7FEB352D) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846CA68B) & 0xFFFFFFFF; x ^= x >> 16
         return x
 

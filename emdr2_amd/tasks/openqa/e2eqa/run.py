@@ -62,7 +62,8 @@ def model_provider(args=None, bert_tokenizer=None, t5_tokenizer=None, arena=None
     model = EMDR2Model(retriever, cfg, args.t5_padded_vocab_size, args.bert_padded_vocab_size, args.topk_retrievals, args.seq_length,
                        args.seq_length_ret, cls_id=t5_tokenizer.cls, sep_id=t5_tokenizer.sep, pad_id=t5_tokenizer.pad,
                        update_retriever=args.update_retriever, retriever_score_scaling=args.retriever_score_scaling,
-                       checkpoint_activations=args.checkpoint_activations, disable_retriever_dropout=args.disable_retriever_dropout,
+                       checkpoint_activations=args.checkpoint_activations and getattr(args, "question_micro_batches", 1) <= 1,
+                       disable_retriever_dropout=args.disable_retriever_dropout,
                        no_query_embedder_training=args.no_query_embedder_training,
                        no_context_embedder_training=args.no_context_embedder_training)
     model.set_recompute_keep_last(getattr(args, "recompute_keep_last_layers", 0))

@@ -26,11 +26,17 @@ def _cross_entropy_forward_step(batch, model, eos_id):
         batch_ = batch
     query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids, labels, loss_mask, _ = process_batch(batch_)
     assert torch.all(query_uid < 0), "query uid can't be positive"
-    lm_logits, topk_log_probs, lm_logits_one_context = model(query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids)
     try:
-        ret_kldiv = bool(getattr(get_args(), 'ret_kldiv', False))
+        ret_kldiv, micro = bool(getattr(get_args(), 'ret_kldiv', False)), int(getattr(get_args(), 'question_micro_batches', 1) or 1)
     except RuntimeError:
-        ret_kldiv = False
+        ret_kldiv, micro = False, 1
+    if micro > 1 and model.training:
+        # --question-micro-batches: forward, loss and backward per group of questions inside the model; the returned loss carries no graph
+        # (train_step skips its backward call)
+        net_loss, stats = model.forward_backward(query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids, labels, loss_mask, eos_id,
+                                                 micro_batches=micro, ret_kldiv=ret_kldiv)
+        return net_loss, {'lm_loss': stats['lm_loss'], 'retriever_loss': stats['retriever_loss']}
+    lm_logits, topk_log_probs, lm_logits_one_context = model(query_uid, q_bert, q_types, q_mask, q_t5, q_t5_len, dec_ids)
     net_loss, stats = emdr2_loss(lm_logits, topk_log_probs, lm_logits_one_context, labels, loss_mask, eos_id, ret_kldiv=ret_kldiv)
     return net_loss, {'lm_loss': stats['lm_loss'], 'retriever_loss': stats['retriever_loss']}
 
@@ -51,7 +57,8 @@ def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler,
         if sink is not None and sink is not optimizer:
             sink.begin_step()
         loss, loss_reduced = forward_step_func(batch, model, eos_id)
-        loss.backward()
+        if loss.requires_grad:                       # (a micro-batched forward step has already back-propagated, group by group)
+            loss.backward()
         if sink is not None:
             sink.finish()                            # buckets were all-reduced (bf16, pre-divided) while the backward ran
         else:

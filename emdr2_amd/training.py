@@ -211,8 +211,24 @@ class FlatAdam(object):
         kernels.FANIN.clear()
         kernels.PREMASK.clear()
 
+    def _ensure_exchange_buffers(self):
+        """world > 1: the bf16 exchange copy of every bucket and the flags buffer of finish() exist BEFORE the first backward, so that a rank
+        that runs out of memory in its very first step can still complete the step's collectives (abort_step) without allocating."""
+        if self._world() == 1 or getattr(self, "_flags", None) is not None:
+            return
+        dev = self.buckets[0]["grad"].device
+        if self.exchange_dtype == "bf16":
+            for b in self.buckets:
+                if b["xchg"] is None:
+                    b["xchg"] = torch.empty(b["n"], dtype=torch.bfloat16, device=dev)
+        self._flags = torch.zeros(1 + len(self.buckets), dtype=torch.int32, device=dev)
+        self._flags_host = torch.zeros(1 + len(self.buckets), dtype=torch.int32)
+        if self.on_device:
+            self._flags_host = self._flags_host.pin_memory()
+
     def begin_step(self):
         self._stale = False
+        self._ensure_exchange_buffers()
         for b in self.buckets:
             b["grad"].zero_()                 # ONE fill per bucket: the producing kernels accumulate straight into their slices (accumulation_target)
             b["handle"], b["launched"], b["ready"] = None, False, False
@@ -287,7 +303,7 @@ class FlatAdam(object):
             self.launches_last_step += 1
             b["handle"] = torch.distributed.all_reduce(b["grad"], group=self.group, async_op=True)
         elif world > 1:
-            if b["xchg"] is None:
+            if b["xchg"] is None:                                  # (normally preallocated: _ensure_exchange_buffers)
                 b["xchg"] = torch.empty(b["n"], dtype=torch.bfloat16, device=b["grad"].device)
             _native.check(_native.lib().emdr2_scale_cast_f32_to_bf16(b["grad"].data_ptr(), b["xchg"].data_ptr(), b["n"], 1.0 / world, _native.stream_ptr()),
                           "scale_cast")                            # pre-divide, then sum (distributed.py:56-58), 16 bits on the wire
@@ -316,18 +332,30 @@ class FlatAdam(object):
                 self.next_bucket += 1
         late = [b["late"] is not None for b in self.buckets]
         aborted = bool(abort)
+        flag_handle = None
         if world > 1:
-            flags = torch.tensor([int(aborted)] + [int(x) for x in late], dtype=torch.int32, device=self.buckets[0]["grad"].device)
-            torch.distributed.all_reduce(flags, op=torch.distributed.ReduceOp.MAX, group=self.group)
-            flags = flags.tolist()
-            aborted, late = bool(flags[0]), [bool(x) for x in flags[1:]]
-        for b, has_late in zip(self.buckets, late):
+            # [abort, late-buffer flag per bucket], MAX over the ranks: persistent buffers (nothing is allocated here: a rank may be out of
+            # memory), the all-reduce in flight while the bucket results are waited for and widened; the host reads it afterwards
+            self._ensure_exchange_buffers()
+            self._flags_host.copy_(torch.tensor([int(aborted)] + [int(x) for x in late], dtype=torch.int32))
+            self._flags.copy_(self._flags_host, non_blocking=True)
+            flag_handle = torch.distributed.all_reduce(self._flags, op=torch.distributed.ReduceOp.MAX, group=self.group, async_op=True)
+        for b in self.buckets:
             if b["handle"] is not None:
                 b["handle"].wait()
                 b["handle"] = None
-                if self.exchange_dtype == "bf16" and not aborted:
+                if self.exchange_dtype == "bf16":                  # (of an aborted step too: its buckets are discarded anyway)
                     _native.check(_native.lib().emdr2_widen_bf16_to_f32(b["xchg"].data_ptr(), b["grad"].data_ptr(), b["n"], _native.stream_ptr()), "widen")
                     self.launches_last_step += 1
+        if flag_handle is not None:
+            flag_handle.wait()
+            flags = self._flags.tolist()                           # the step's one host read of the exchange (everything above is enqueued)
+            aborted, late = bool(flags[0]), [bool(x) for x in flags[1:]]
+        if aborted:                                                # every rank knows: the late buffers' all-reduces are skipped by all of them
+            late = [False] * len(self.buckets)
+            for b in self.buckets:
+                b["late"] = None
+        for b, has_late in zip(self.buckets, late):
             if has_late:                                           # contributions that missed their bucket's all-reduce (pattern change) on SOME rank
                 if b["late"] is None:
                     b["late"] = torch.zeros(b["n"], dtype=torch.float32, device=b["grad"].device)
@@ -424,9 +452,12 @@ class RetentionGuard(object):
     behind this rank -- before that point of an attempt its peers cannot be told and the failure is raised.  Used by bench_e2e.py and by
     the training task."""
 
-    def __init__(self, model, optimizer, keep=0, reader=0, context=0, query=0, forward_progress=None, log=None):
+    def __init__(self, model, optimizer, keep=0, reader=0, context=0, query=0, forward_progress=None, log=None, micro=1, batch=None):
         self.model, self.opt = model, optimizer
         self.plan = {"keep": int(keep), "reader": int(reader), "context": int(context), "query": int(query), "thinned": 0}
+        # question micro-batches of a step (EMDR2Model.forward_backward; the step function reads `guard.micro`): with m > 1 nothing is
+        # re-run and there is no retention plan to thin -- a step that still does not fit is split finer (m doubles while it divides the batch)
+        self.micro, self.batch = max(1, int(micro)), batch
         self.reruns = 0
         self.forward_progress = forward_progress
         self.log = log or (lambda msg: None)
@@ -452,6 +483,11 @@ class RetentionGuard(object):
             p["keep"] -= 1
         elif p["reader"] > 0:
             p["reader"] = max(0, p["reader"] - 2)
+        elif self.micro > 1 and self.batch and self.batch % (2 * self.micro) == 0:
+            self.micro *= 2
+            p["thinned"] += 1
+            self.log("step split into %d question micro-batches after an allocation failure" % self.micro)
+            return True
         else:
             return False
         p["thinned"] += 1
@@ -464,18 +500,25 @@ class RetentionGuard(object):
         world = torch.distributed.get_world_size() if (torch.distributed.is_available() and torch.distributed.is_initialized()) else 1
         for attempt in range(8):
             mark = self.forward_progress() if self.forward_progress else None
+            failed = False
             try:
                 return step_once()
             except torch.cuda.OutOfMemoryError:
                 if world > 1 and self.forward_progress and self.forward_progress() == mark:
                     raise
+                if world > 1 and getattr(self.opt, "abort_step", None) is None:
+                    raise                                          # (an optimizer without the abort protocol cannot take its peers along)
+                failed = True
+            except StepAborted:
+                pass
+            if failed:
+                # outside the except block: the failed step's activations were held by the traceback; drop them BEFORE the exchange is
+                # completed (abort_step itself allocates nothing: FlatAdam._ensure_exchange_buffers)
+                gc.collect()
+                torch.cuda.empty_cache()
                 abort = getattr(self.opt, "abort_step", None)
                 if abort is not None:
                     abort()
-                elif world > 1:
-                    raise                                          # (an optimizer without the abort protocol cannot take its peers along)
-            except StepAborted:
-                pass
             self.opt.zero_grad()
             gc.collect()
             torch.cuda.empty_cache()                               # first: allocator fragmentation -- give the blocks back, same step again

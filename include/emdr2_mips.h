@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EMDR2_ABI_VERSION 2
+#define EMDR2_ABI_VERSION 3
 
 #define EMDR2_OK 0
 #define EMDR2_E_BADARG (-1)      /* bad size / alignment / null pointer */
@@ -135,6 +135,23 @@ int emdr2_mips_search_exact_f32(const void *tiled, int64_t n_rows, int dim, int6
 int emdr2_mips_merge_f32(const float *dist_in, const int32_t *idx_in, const int64_t *row_in, int n_shards, int n_q, int k,
                          float *out_dist, int32_t *out_idx, int64_t *out_row, emdr2_stream_t stream);
 
+
+/*
+ * The sharded search's exchange format (replaces the reference's gather of per-device partial results + two broadcasts,
+ * emdr2_index.py:284-295, emdr2_model.py:451-452): ONE 16-byte little-endian record per (query, slot),
+ *     { int64 global row | int32 doc id | uint32 score bits (fp16 in the low half; fp32 when f32 != 0) },   row = id = -1 in empty slots.
+ * emdr2_mips_search_records = emdr2_mips_search / _search_f32 whose last kernel writes records [n_q, k] -- i.e. straight into the send
+ * buffer of the ONE all-gather of a search; emdr2_mips_merge_records = emdr2_mips_merge / _merge_f32 reading the gathered buffer
+ * [n_shards, n_q, k] as it arrived; emdr2_mips_pack_records overwrites records rows sel[i] from (dist, idx, row) arrays (queries that the
+ * all-exact path re-did).  records pointers are 16-byte aligned.
+ */
+int emdr2_mips_search_records(const void *tiled, int64_t n_rows, int dim, int64_t row_base, const float *emax_sq, const void *queries, int n_q,
+                              int k, const int32_t *ids, int f32, void *out_records, uint32_t *out_flags, void *workspace,
+                              size_t workspace_bytes, emdr2_stream_t stream);
+int emdr2_mips_merge_records(const void *records_in, int n_shards, int n_q, int k, int f32, void *out_dist, int32_t *out_idx, int64_t *out_row,
+                             emdr2_stream_t stream);
+int emdr2_mips_pack_records(const void *dist, const int32_t *idx, const int64_t *row, const int32_t *sel, int n_sel, int k, int f32,
+                            void *records, emdr2_stream_t stream);
 
 /* Diagnostics for tests: fp32 MFMA scores S~[n_q, n_rows] (row-major float) of the scan kernel's
  * arithmetic, for measuring |S~ - exact| against the bound used by the validity check. */

@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version(lib):
-    assert lib.emdr2_abi_version() == 2          # r04: dstat scratch of the attention backward is four arrays
+    assert lib.emdr2_abi_version() == 3          # r05: packed-record search / merge entry points
 
 
 def test_layout_bytes_and_argument_validation(lib):

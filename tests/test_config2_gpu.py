@@ -29,7 +29,7 @@ def test_config2_step_at_benchmark_shape_ids_layouts_gradients_and_bit_reproduci
     from emdr2_amd.model import kernels as K
     from emdr2_amd.model.emdr2_model import emdr2_loss
     args = types.SimpleNamespace(batch=64, layers=12, seq=512, seq_ret=256, dropout=0.1, keep_last_layers="0", selective_layers="12,6", no_packing=False,
-                                 reindex_rows_per_step=0, rows=2_000_000)
+                                 reindex_rows_per_step=0, rows=2_000_000, micro_batches=1)
     ctx = bench_e2e.setup(args, 0, 1, topk=50)
     model, opt, retr = ctx.model, ctx.opt, ctx.retriever
     bt = ctx.make_batch()

@@ -42,6 +42,17 @@ class _OracleShard(object):
             d, i, r = mo.topk(self._rows, q, k, ids=self.ids, row_base=self.row_base, return_rows=True)
         return torch.from_numpy(d), torch.from_numpy(i), torch.from_numpy(r), torch.zeros(q.shape[0], dtype=torch.int32)
 
+    def search_records(self, queries, k, f32=False, out=None):
+        """HipIndexShard.search_records: the same answer as 16-byte records (include/emdr2_mips.h) in the caller's gather buffer."""
+        d, i, r, flags = self.search(queries, k)
+        rec = np.zeros(d.shape, dtype=RECORD)
+        rec["row"], rec["idx"], rec["bits"] = r.numpy(), i.numpy(), d.numpy().view(np.uint16).astype(np.uint32)
+        out.copy_(torch.from_numpy(rec.view(np.uint8).reshape(d.shape + (16,))))
+        return out, flags
+
+
+RECORD = np.dtype([("row", "<i8"), ("idx", "<i4"), ("bits", "<u4")])      # include/emdr2_mips.h: the exchange format of a sharded search
+
 
 def _merge_cpu(dist_t, idx_t, row_t):
     """(score desc, global row asc) merge of [S, Q, k] lists; the HIP merge kernel's contract."""
@@ -66,8 +77,10 @@ def _worker(rank, world, port, n_rows, out_dir):
         def _make_shard(self, dim, n, base):
             return _OracleShard(dim, n, base)
 
-        def _merge(self, d, i, r):
-            return _merge_cpu(d, i, r)
+        def _merge_records(self, gathered, f32):
+            rec = gathered.numpy().view(RECORD).reshape(gathered.shape[:3])
+            d = torch.from_numpy(rec["bits"].astype(np.uint16).view(np.float16))
+            return _merge_cpu(d, torch.from_numpy(rec["idx"].copy()), torch.from_numpy(rec["row"].copy()))
 
     case = mips_cases.case_realistic_k100()
     rows, ids = case["rows"][:n_rows], case["ids"][:n_rows]

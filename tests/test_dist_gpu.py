@@ -162,7 +162,7 @@ def test_plain_bench_command_with_two_gpus_launches_its_own_ranks_and_prints_bot
     r = _plain_bench()
     assert r["metric"] == "mips_queries_per_sec" and r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "strong"
     assert r["config"]["rows_per_rank"] == [1000000, 1000000] and r["config"]["unproven_queries"] == 0
-    assert r["config"]["allgather_bytes_per_rank"] == 3 * 512 * 50 * 8 and r["config"]["allgather_plus_merge_ms"] > 0
+    assert r["config"]["allgather_bytes_per_rank"] == 512 * 50 * 16 and r["config"]["allgather_plus_merge_ms"] > 0      # one 16-byte record per (query, slot)
     assert r["roofline"]["frac"] > 0
     e = r["e2e"]
     assert "error" not in e, e
@@ -177,10 +177,23 @@ def test_a_rank_running_out_of_memory_mid_step_is_recovered_by_all_ranks_togethe
     """rank 1's second step raises an allocation failure after its forward while rank 0 carries on into the backward and
     its bucket all-reduces.  Rank 1 completes the step's collectives (FlatAdam.abort_step), both ranks discard the step, run it again, and
     end with bit-identical replicas; nothing hangs, one re-run is reported."""
-    r = _plain_bench({"EMDR2_BENCH_INJECT_OOM": "1,2"}, ["--selective-layers", "2,0"])
+    r = _plain_bench({"EMDR2_BENCH_INJECT_OOM": "1,2"}, ["--selective-layers", "2,0", "--micro-batches", "1"])
     e = r["e2e"]
     assert "error" not in e, e
     assert e["config"]["steps_rerun_after_out_of_memory"] == 1
+    cs = e["config"]["replica_parameter_checksums"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs
+
+
+def test_out_of_memory_in_the_very_first_step_between_two_question_groups():
+    """the failure comes in rank 1's FIRST step -- before any bucket has ever been exchanged, so the exchange buffers and the
+    flags buffer must already exist (FlatAdam._ensure_exchange_buffers: abort_step allocates nothing) -- and in the micro-batched step
+    (EMDR2Model.forward_backward), between group 0's forward and its backward, while rank 0 runs all its groups."""
+    r = _plain_bench({"EMDR2_BENCH_INJECT_OOM": "1,1"}, ["--micro-batches", "2"])
+    e = r["e2e"]
+    assert "error" not in e, e
+    assert e["config"]["steps_rerun_after_out_of_memory"] == 1 and e["config"]["question_micro_batches"] == 2
+    assert e["config"]["recompute_tflop_per_step"] == 0
     cs = e["config"]["replica_parameter_checksums"]
     assert len(cs) == 2 and cs[0] == cs[1], cs
 

@@ -163,6 +163,47 @@ def test_shard_count_invariance_with_hip_merge():
         assert np.array_equal(mr.cpu().numpy(), r1)
 
 
+RECORD = np.dtype([("row", "<i8"), ("idx", "<i4"), ("bits", "<u4")])      # include/emdr2_mips.h: the exchange format of a sharded search
+
+
+@pytest.mark.parametrize("f32", [False, True])
+def test_packed_records_carry_the_search_result_and_merge_like_the_three_arrays(f32):
+    """r05: what a sharded search exchanges is ONE 16-byte record per (query, slot), written by the finalize kernel into the gather buffer
+    and read from there by the merge kernel.  Records == the three-array outputs (decoded with numpy by the layout the header states),
+    queries re-done by the all-exact path included; merged records == merged arrays == the single-shard search, for 2 / 3 / 8 shards and a
+    shard with fewer than k rows."""
+    from emdr2_amd.data.emdr2_index import merge_shard_records, shard_bounds
+    for case in (mips_cases.case_realistic(), mips_cases.case_exact_ties()):
+        rows, q, k, ids = case["rows"], case["queries"], case["k"], case["ids"]
+        qt = torch.from_numpy(q).cuda()
+        sh = _shard(rows, ids)
+        d1, i1, r1, _ = sh.search_f32(qt, k) if f32 else sh.search(qt, k)
+        rec, flags = sh.search_records(qt, k, f32=f32)
+        torch.cuda.synchronize()
+        assert int(flags.abs().sum()) == 0                                       # (re-done queries have their flags cleared)
+        dec = rec.cpu().numpy().view(RECORD).reshape(q.shape[0], k)
+        assert np.array_equal(dec["row"], r1.cpu().numpy()) and np.array_equal(dec["idx"], i1.cpu().numpy())
+        bits = d1.cpu().numpy().view(np.uint32) if f32 else d1.cpu().numpy().view(np.uint16).astype(np.uint32)
+        assert np.array_equal(dec["bits"], bits)
+        for world in (2, 3, 8, rows.shape[0] // 7):                              # the last: 7-row shards, fewer rows than k
+            world = int(world)
+            if world > 64:
+                bounds = [(lo, min(lo + 7, rows.shape[0])) for lo in range(0, 7 * 40, 7)]      # 40 shards of 7 rows over the first 280 rows
+                ref = _shard(rows[:280], ids[:280] if ids is not None else None)
+                dref, iref, rref, _ = ref.search_f32(qt, k) if f32 else ref.search(qt, k)
+            else:
+                bounds, (dref, iref, rref) = shard_bounds(rows.shape[0], world), (d1, i1, r1)
+            gathered = torch.empty((len(bounds), q.shape[0], k, 16), dtype=torch.uint8, device="cuda")
+            for s_, (lo, hi) in enumerate(bounds):
+                part = _shard(rows[lo:hi], ids[lo:hi] if ids is not None else None, row_base=lo)
+                out, _ = part.search_records(qt, k, f32=f32, out=gathered[s_])     # straight into its slice of the gather buffer
+                assert out.data_ptr() == gathered[s_].data_ptr()
+            md, mi, mr = merge_shard_records(gathered, f32=f32)
+            torch.cuda.synchronize()
+            assert torch.equal(md.view(torch.int32 if f32 else torch.int16), dref.view(torch.int32 if f32 else torch.int16))
+            assert torch.equal(mi, iref) and torch.equal(mr, rref)
+
+
 def test_tie_heavy_shards_merge_like_single_search():
     from emdr2_amd.data.emdr2_index import merge_shard_results, shard_bounds
     case = mips_cases.case_exact_ties()
