@@ -93,6 +93,12 @@ SIGNATURES.update({
     "emdr2_attention_varlen_bwd": (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _i64, _i64,
                                           _vp, _vp, _vp, _vp, _i64, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp]),
 })
+SIGNATURES["emdr2_attention_splitkv_plan"] = (_i32, [_i32, _i32, _i32, _i32, ctypes.POINTER(_i32), ctypes.POINTER(_sz), ctypes.POINTER(_sz)])
+SIGNATURES["emdr2_attention_fwd_splitkv"] = (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _vp, _i64,
+                                                      _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u32, _vp, _vp, _i32, _vp, _sz, _vp])
+SIGNATURES["emdr2_attention_bwd_splitkv"] = (_i32, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _vp, _vp, _i64, _i64, _vp, _vp,
+                                                      _i64, _i64, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _f32, _f32, _u32,
+                                                      _i32, _vp, _sz, _vp])
 SIGNATURES["emdr2_gemm_nt_lse_bf16"] = (_i32, [_vp, _i64, _vp, _i64, _i32, _i32, _i32, _f32, _vp, _vp, _vp, _vp, _vp, _vp])
 SIGNATURES["emdr2_retriever_prior_fwd"] = (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])
 SIGNATURES["emdr2_retriever_prior_bwd"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp])

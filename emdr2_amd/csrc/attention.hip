@@ -38,6 +38,14 @@ struct AttnParams {
     // NULL = the dense [batch, s] layout.  With cu_q the row statistics are laid out [heads, tq]; sq / sk are then the LONGEST sequence.
     const int *cu_q, *cu_k;
     long long tq;
+    // split keys (few queries, very many keys: the FiD decoder's 32 positions over the ~20,000 packed keys of a question's K passages, where
+    // one workgroup per (question, head) walking all key blocks leaves most of the chip idle): the key blocks of a (batch, head, query block)
+    // are dealt to `ksplit` workgroups, each leaves its UNNORMALISED partial (O fp32, m in log2 units, l) in the workspace and
+    // attention_combine_kernel folds them.  ksplit == 1: none of this.
+    int ksplit;
+    unsigned base_grid;           // workgroups of one split (attn_grid)
+    float *part_o, *part_m, *part_l;   // [ksplit][stat_n][64], [ksplit][stat_n] x 2
+    long long stat_n;
 };
 
 // exchange between lane i and lane i + 32 (the two halves of a wave hold the two key subsets of one query): v_permlane32_swap with the value
@@ -77,7 +85,8 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     int qblk, b, n;
-    if (!attn_decode(blockIdx.x, (p.sq + QB - 1) / QB, p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / p.base_grid) : 0;
+    if (!attn_decode(p.ksplit > 1 ? (int)(blockIdx.x - split * p.base_grid) : (int)blockIdx.x, (p.sq + QB - 1) / QB, p.batch * p.heads, p.heads, qblk, b, n)) return;
     // this sequence's extent: dense = [b * s, b * s + s) with a batch stride; packed = rows [cu[b], cu[b+1])
     int sq = p.sq, sk = p.sk;
     long long qrow0 = (long long)b * p.sq, krow0 = (long long)b * p.sk;            // first row of the sequence in ids / o / (k)
@@ -97,7 +106,10 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + (k_off + (long long)n * p.k_sn) * 2 + pslot * 16;        // + key * k_ss * 2
     const char *v_src = p.v + (v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = (sk + KB - 1) / KB;
+    const int nblk_all = (sk + KB - 1) / KB;
+    // this workgroup's key blocks [blk_lo, nblk): all of them, or its share of a split launch (possibly none: more splits than blocks)
+    const int blk_lo = p.ksplit > 1 ? (int)((long long)nblk_all * split / p.ksplit) : 0;
+    const int nblk = p.ksplit > 1 ? (int)((long long)nblk_all * (split + 1) / p.ksplit) : nblk_all;
     auto issue = [&](int blk, int stage) {                                     // dense: sk % 32 == 0 (checked on the host); packed: any sk
         char *sb = smem + stage * 16384;
 #pragma unroll
@@ -110,7 +122,7 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     };
     // the first K / V block goes out before anything else touches global memory: short (packed) sequences have only 2 - 4 blocks per
     // workgroup, and a prologue that first waits for its Q rows and key ids and only then starts the DMA pays the memory latency twice
-    issue(0, 0);
+    if (blk_lo < nblk) issue(blk_lo, 0);
 
     // Q fragments (B operand of S^T = K Q^T): for k-step t the lane holds d = 16t + 8*half .. +8
     const char *qrow = p.q + (q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2;
@@ -122,7 +134,7 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     uint32_t vtr[2][2], kra[4];
     tr_addresses((uint32_t)(uintptr_t)smem + 8192, lane, vtr);
     row_frag_addresses((uint32_t)(uintptr_t)smem, lane, kra);
-    for (int blk = wave; blk < nblk; blk += NW) {
+    for (int blk = blk_lo + wave; blk < nblk; blk += NW) {
         const int key = blk * KB + lane;
         const unsigned long long w = __builtin_amdgcn_ballot_w64(key < sk && p.ids_k[krow0 + (key < sk ? key : sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
@@ -147,7 +159,7 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     // itself it would put the wait for the Q rows at their first use inside the loop, as vmcnt(0) -- and drain the look-ahead DMA with it
     asm volatile("s_waitcnt vmcnt(0)" : "+v"(qf[0]), "+v"(qf[1]), "+v"(qf[2]), "+v"(qf[3])::"memory");
     int stage = 0;
-    for (int blk = 0; blk < nblk; ++blk, stage ^= 1) {
+    for (int blk = blk_lo; blk < nblk; ++blk, stage ^= 1) {
         // this block's pieces are the newest DMA of this wave (the next block's go out after the barrier)
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         // raw barrier: what must be ordered here is LDS only -- the mask words of the prologue and (through each wave's own wait above) the tiles
@@ -160,7 +172,7 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
         const int key0 = blk * KB;
         // A block whose keys are all masked for every query of this wave contributes exp(-10000 - m) == 0 exactly once each query has
         // seen a real key (m > -7000): skip it.  Rows that are masked everywhere (padded queries) need every block, hence any_qpad.
-        if ((kmask == 0ull || (CAUSAL && key0 > q0 + QW - 1)) && !any_qpad && blk > 0 &&
+        if ((kmask == 0ull || (CAUSAL && key0 > q0 + QW - 1)) && !any_qpad && blk > blk_lo &&
             __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
             continue;
         const uint32_t av0[2] = {vtr[0][0] + (uint32_t)(stage * 16384), vtr[0][1] + (uint32_t)(stage * 16384)};
@@ -171,7 +183,7 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
             const uint32_t km = (uint32_t)(kmask >> (32 * j));
             const int kb0 = key0 + 32 * j;
             if (kb0 >= sk) continue;                                              // the second half of the last block does not exist
-            if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > 0 || j > 0) &&
+            if ((km == 0u || (CAUSAL && kb0 > q0 + QW - 1)) && !any_qpad && (blk > blk_lo || j > 0) &&
                 __builtin_amdgcn_ballot_w64(mrun > -7000.f) == ~0ull)
                 continue;
             auto dropout_and_pv = [&](floatx16 &sacc) {
@@ -271,6 +283,20 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
         }
     }
 
+    if (p.ksplit > 1) {
+        // partial of this key range: unnormalised O, reference point m (log2 units), sum l -- (-3e38, 0, 0) when the range was empty
+        if (qvalid) {
+            const long long si = (long long)split * p.stat_n + stat0 + qi;
+            float *orow = p.part_o + si * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4 *)(orow + j * 32 + 8 * g + 4 * hi) = make_float4(oacc[j][4 * g], oacc[j][4 * g + 1], oacc[j][4 * g + 2], oacc[j][4 * g + 3]);
+            if (hi == 0) { p.part_m[si] = mrun; p.part_l[si] = lrun; }
+        }
+        return;
+    }
     // ---- normalise and store O[q, d]: lane q holds d = j*32 + (r&3) + 8(r>>2) + 4*half --------------------------------------
     if (qvalid) {
         const float inv = ik / lrun;                                 // survivors of the attention dropout are scaled here, once
@@ -291,14 +317,49 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     }
 }
 
+// Fold the partials of a split launch: O = sum_s 2^(m_s - M) O_s / sum_s 2^(m_s - M) l_s (x 1 / (1 - p) of the attention dropout), statistics
+// (M ln 2, L) exactly as one workgroup walking all the keys leaves them.  One wave per query row (dense-q launches only): lane = d.
+__global__ void __launch_bounds__(256) attention_combine_kernel(AttnParams p, float keep_scale)
+{
+    const long long si = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = threadIdx.x & 63;
+    if (si >= p.stat_n) return;
+    float M = -3.0e38f;
+    for (int s = 0; s < p.ksplit; ++s) M = fmaxf(M, p.part_m[(long long)s * p.stat_n + si]);
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) {
+        const long long i = (long long)s * p.stat_n + si;
+        const float w = __builtin_amdgcn_exp2f(p.part_m[i] - M);
+        L += w * p.part_l[i];
+        acc += w * p.part_o[i * 64 + d];
+    }
+    // si = (b * heads + n) * sq + q  ->  o row (b * sq + q) * heads + n
+    const long long bn = si / p.sq, q = si - bn * p.sq, b = bn / p.heads, n = bn - b * p.heads;
+    ((__bf16 *)p.o)[((b * p.sq + q) * p.heads + n) * 64 + d] = (__bf16)(acc * (keep_scale / L));
+    if (d == 0 && p.m) { p.m[si] = M * 0.6931471805599453f; p.l[si] = L; }
+}
+
 } // namespace
+
+// how many ways to split the keys of a launch with `wgs` (batch x heads x query blocks) workgroups and up to `nblk` key blocks each: only
+// when the launch cannot fill the chip by itself (4 workgroups per CU resident) and the key walk is long
+static int attention_ksplit(long long wgs, int nblk, int cus)
+{
+    if (wgs <= 0 || wgs * 2 > 4ll * cus || nblk < 16) return 1;
+    long long want = (6ll * cus + wgs - 1) / wgs;                                 // ~1.5 rounds of resident workgroups
+    const long long most = nblk / 4;                                              // >= 4 key blocks per workgroup
+    if (want > most) want = most;
+    if (want > 64) want = 64;
+    return want < 2 ? 1 : (int)want;
+}
 
 static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
                                 const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k, int batch, int heads, int sq, int sk,
                                 int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, const int32_t *cu_q, const int32_t *cu_k,
-                                int64_t total_q, double pairs, void *stream)
+                                int64_t total_q, double pairs, void *stream, int ksplit = 1, void *ws = nullptr, size_t ws_bytes = 0)
 {
     if (!q || !k || !v || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15)))) return -1;
     if (head_dim != 64 || sk < 1 || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
     if (!cu_k && (sk < 32 || (sk & 31))) return -4;                                  // dense keys: whole 32-key steps (padded queries average over exactly sk keys)
     if (cu_q && total_q < 1) return -1;
@@ -309,13 +370,23 @@ static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.q_sb = q_sb; p.q_ss = q_ss; p.q_sn = q_sn; p.k_sb = k_sb; p.k_ss = k_ss; p.k_sn = k_sn; p.v_sb = v_sb; p.v_ss = v_ss; p.v_sn = v_sn;
     p.heads = heads; p.sq = sq; p.sk = sk; p.causal = causal; p.scale = scale; p.drop_p = drop_p; p.seed = seed;
     p.batch = batch; p.cu_q = cu_q; p.cu_k = cu_k; p.tq = total_q;
-    dim3 grid(attn_grid((sq + QB - 1) / QB, batch * heads, heads));
+    p.ksplit = ksplit; p.base_grid = attn_grid((sq + QB - 1) / QB, batch * heads, heads);
+    p.stat_n = (long long)batch * heads * sq;
+    p.part_o = p.part_m = p.part_l = nullptr;
+    if (ksplit > 1) {
+        if (ws_bytes < (size_t)ksplit * p.stat_n * 66 * sizeof(float)) return -2;
+        p.part_o = (float *)ws; p.part_m = p.part_o + (size_t)ksplit * p.stat_n * 64; p.part_l = p.part_m + (size_t)ksplit * p.stat_n;
+    }
+    dim3 grid(p.base_grid * (unsigned)ksplit);
     const size_t lds = 2 * 16384 + (size_t)((sk + KB - 1) / KB) * 8;            // <= 40 KiB (sk <= 65536)
     OpsTimer timer(OPS_ATTN_FWD, 4.0 * heads * pairs * 64, (hipStream_t)stream);
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_fwd_kernel<true, true>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_fwd_kernel<true, false>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     else if (causal) hipLaunchKernelGGL((attention_fwd_kernel<false, true>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_fwd_kernel<false, false>), grid, dim3(NW * 64), lds, (hipStream_t)stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(attention_combine_kernel, dim3((unsigned)((p.stat_n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                           drop_p > 0.f ? emdr2_keep_scale(drop_p) : 1.f);
     return hipGetLastError() == hipSuccess ? 0 : -3;
 }
 
@@ -325,6 +396,33 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
 {
     return attention_fwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, ids_q, ids_k, batch, heads, sq, sk, head_dim, causal, scale, drop_p,
                                 seed, m, l, nullptr, nullptr, 0, (double)batch * sq * sk, stream);
+}
+
+// Split-key plan of a launch with DENSE queries [batch, max_sq] over up to max_sk keys per sequence: number of splits (1 = do not split) and
+// the workspace bytes the forward / backward launches then need (emdr2_ops.h).
+extern "C" int emdr2_attention_splitkv_plan(int batch, int heads, int max_sq, int max_sk, int *ksplit, size_t *fwd_bytes, size_t *bwd_bytes)
+{
+    if (!ksplit || !fwd_bytes || !bwd_bytes || batch < 1 || heads < 1 || max_sq < 1 || max_sk < 1) return -1;
+    int dev = 0, cus = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
+    const long long wgs = (long long)batch * heads * ((max_sq + QB - 1) / QB);
+    const int ks = attention_ksplit(wgs, (max_sk + KB - 1) / KB, cus);
+    const size_t stat_n = (size_t)batch * heads * max_sq;
+    *ksplit = ks;
+    *fwd_bytes = ks > 1 ? (size_t)ks * stat_n * 66 * sizeof(float) : 0;
+    *bwd_bytes = ks > 1 ? (size_t)ks * stat_n * 64 * sizeof(float) : 0;
+    return 0;
+}
+
+extern "C" int emdr2_attention_fwd_splitkv(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                                  const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k,
+                                                  const int32_t *cu_k, int64_t pairs, int batch, int heads, int sq, int max_sk,
+                                                  int head_dim, int causal, float scale, float drop_p, uint32_t seed, float *m, float *l, int ksplit, void *ws,
+                                                  size_t ws_bytes, void *stream)
+{
+    return attention_fwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, ids_q, ids_k, batch, heads, sq, max_sk, head_dim, causal, scale,
+                                drop_p, seed, m, l, nullptr, cu_k, 0, (double)pairs, stream, ksplit, ws, ws_bytes);
 }
 
 extern "C" int emdr2_attention_varlen_fwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,

@@ -47,6 +47,11 @@ struct BwdParams {
     // packed operands (attention.hip: AttnParams): sequence b owns rows [cu[b], cu[b+1]); statistics [heads, tq] when cu_q is given
     const int *cu_q, *cu_k;
     long long tq;
+    // split keys (attention.hip: AttnParams): the dq kernel's key blocks dealt to `ksplit` workgroups, fp32 partial dQ [ksplit][stat_n][64]
+    // folded by attention_dq_combine_kernel; the dk / dv kernel is parallel over keys already
+    int ksplit;
+    unsigned base_grid;
+    float *part_dq;
 };
 
 // the sequence's extent and operand offsets, dense or packed (see attention.hip)
@@ -88,7 +93,8 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, hi = lane >> 5;
     int qblk, b, n;
-    if (!attn_decode(blockIdx.x, (p.sq + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, qblk, b, n)) return;
+    const int split = p.ksplit > 1 ? (int)(blockIdx.x / p.base_grid) : 0;
+    if (!attn_decode(p.ksplit > 1 ? (int)(blockIdx.x - split * p.base_grid) : (int)blockIdx.x, (p.sq + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, qblk, b, n)) return;
     const SeqExtent ex = seq_extent(p, b, n);
     const int sq = ex.sq, sk = ex.sk;
     if (qblk * (BNW * 32) >= sq || sk < 1) return;
@@ -101,7 +107,9 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const int prow = wave * 8 + (lane >> 3), pslot = (lane & 7) ^ tile_swz(wave * 8 + (lane >> 3));
     const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2 + pslot * 16;
     const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
-    const int nblk = (sk + 63) / 64;
+    const int nblk_all = (sk + 63) / 64;
+    const int blk_lo = p.ksplit > 1 ? (int)((long long)nblk_all * split / p.ksplit) : 0;             // this workgroup's key blocks [blk_lo, nblk)
+    const int nblk = p.ksplit > 1 ? (int)((long long)nblk_all * (split + 1) / p.ksplit) : nblk_all;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
@@ -112,8 +120,8 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
             __builtin_amdgcn_global_load_lds((gptr_t *)(v_src + key * p.v_ss * 2), (lptr_t *)(sb + 8192 + (wave + BNW * i) * 1024), 16, 0, 0);
         }
     };
-    issue(0, 0);                     // before the fragment / statistics loads below: a short sequence must not pay the memory latency twice
-    if (nblk > 1) issue(1, 1);
+    if (blk_lo < nblk) issue(blk_lo, 0);    // before the fragment / statistics loads below: a short sequence must not pay the memory latency twice
+    if (blk_lo + 1 < nblk) issue(blk_lo + 1, 1);
 
     bf16x8 qf[4], dof[4];
     load_row_frags(p.q + (ex.q_off + (long long)qc * p.q_ss + (long long)n * p.q_sn) * 2, hi, qf);
@@ -141,7 +149,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const float sc = p.scale2;
     const float pm = p.m[si] * L2E + __log2f(p.l[si]);                  // P = exp2(s2 - pm)
 
-    for (int blk = wave; blk < nblk; blk += BNW) {
+    for (int blk = blk_lo + wave; blk < nblk; blk += BNW) {
         const int key = blk * 64 + lane;
         const unsigned long long w = __builtin_amdgcn_ballot_w64(key < sk && p.ids_k[ex.krow0 + (key < sk ? key : sk - 1)] != 0);
         if (lane == 0) kmask_s[blk] = w;
@@ -165,7 +173,7 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     }
 
     int stage = 0;
-    for (int blk = 0; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
+    for (int blk = blk_lo; blk < nblk; ++blk, stage = stage == 2 ? 0 : stage + 1) {
         if (blk + 1 < nblk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (8 / BNW)) : "memory");      // all but the next block's pieces
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                        // raw barrier (no fence: the look-ahead DMA stays in flight)
@@ -245,6 +253,17 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
             }
         }
     }
+    if (p.ksplit > 1) {                                                           // partial dQ of this key range (unscaled, fp32)
+        if (qvalid) {
+            float *prow = p.part_dq + ((long long)split * p.stat_n + si) * 64;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int g = 0; g < 4; ++g)
+                    *(float4 *)(prow + j * 32 + 8 * g + 4 * hi) = make_float4(dqacc[j][4 * g], dqacc[j][4 * g + 1], dqacc[j][4 * g + 2], dqacc[j][4 * g + 3]);
+        }
+        return;
+    }
     if (qvalid) {
         const float qsc = p.scale * ik;
         uint16_t *drow = (uint16_t *)p.dq + ex.dq_off + (long long)qi * p.dq_ss + n * 64;
@@ -257,6 +276,18 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
                                                   pack_bf16(dqacc[j][4 * g + 2] * qsc, dqacc[j][4 * g + 3] * qsc));
             }
     }
+}
+
+// dQ = (sum of the splits' partials) x scale / (1 - p): dense-q launches only; one wave per query row, lane = d, partials in split order
+__global__ void __launch_bounds__(256) attention_dq_combine_kernel(BwdParams p, float qsc)
+{
+    const long long si = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int d = threadIdx.x & 63;
+    if (si >= p.stat_n) return;
+    float acc = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) acc += p.part_dq[((long long)s * p.stat_n + si) * 64 + d];
+    const long long bn = si / p.sq, q = si - bn * p.sq, b = bn / p.heads, n = bn - b * p.heads;
+    ((__bf16 *)p.dq)[b * p.dq_sb + q * p.dq_ss + n * 64 + d] = (__bf16)(acc * qsc);
 }
 
 // ========================================================== dk, dv ===================================================================
@@ -497,9 +528,10 @@ static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
                                 const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
                                 int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k, const float *m, const float *l, float *dstat, int batch,
                                 int heads, int sq, int sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed, const int32_t *cu_q, const int32_t *cu_k,
-                                int64_t total_q, double pairs, void *stream)
+                                int64_t total_q, double pairs, void *stream, int ksplit = 1, void *ws = nullptr, size_t ws_bytes = 0)
 {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15)))) return -1;
     if (head_dim != 64 || sk < 1 || sk > 65536) return -4;
     if (!cu_k && (sk < 32 || (sk & 31))) return -4;
     if (cu_q && total_q < 1) return -1;
@@ -520,13 +552,18 @@ static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
     p.stat_n = cu_q ? (long long)heads * total_q : (long long)batch * heads * sq;
     if (p.stat_n * 16 >= (1ll << 32) || q_ss >= (1 << 22) || heads >= (1 << 16)) return -4;     // 32-bit lane offsets of the dk/dv kernel's staging
     p.keep_scale = emdr2_keep_scale(drop_p); p.inv_keep_scale = 1.f / p.keep_scale; p.scale2 = scale * L2E; p.drop_thr = emdr2_drop_thr(drop_p);
+    p.ksplit = ksplit; p.base_grid = attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads, heads); p.part_dq = (float *)ws;
+    if (ksplit > 1 && ws_bytes < (size_t)ksplit * p.stat_n * 64 * sizeof(float)) return -2;
     OpsTimer timer(OPS_ATTN_BWD, 10.0 * heads * pairs * 64, (hipStream_t)stream);
-    const dim3 dq_grid(attn_grid((sq + BNW * 32 - 1) / (BNW * 32), batch * heads, heads));
+    const dim3 dq_grid(p.base_grid * (unsigned)ksplit);
     const size_t dq_lds = 3 * 16384 + (size_t)((sk + 63) / 64) * 8;
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, true>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dq_kernel<true, false>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
     else if (causal) hipLaunchKernelGGL((attention_bwd_dq_kernel<false, true>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attention_bwd_dq_kernel<false, false>), dq_grid, dim3(BNW * 64), dq_lds, (hipStream_t)stream, p);
+    if (ksplit > 1)
+        hipLaunchKernelGGL(attention_dq_combine_kernel, dim3((unsigned)((p.stat_n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, p,
+                           scale * (drop_p > 0.f ? p.keep_scale : 1.f));
     const dim3 kv_grid(attn_grid((sk + KNW * 32 - 1) / (KNW * 32), batch * heads, heads));
     if (drop_p > 0.f && causal) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, true>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
     else if (drop_p > 0.f) hipLaunchKernelGGL((attention_bwd_dkv_kernel<true, false>), kv_grid, dim3(KNW * 64), 0, (hipStream_t)stream, p);
@@ -542,6 +579,17 @@ extern "C" int emdr2_attention_bwd(const void *q, int64_t q_sb, int64_t q_ss, in
 {
     return attention_bwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, dout, dq, dq_sb, dq_ss, dk, dv, dkv_sb, dkv_ss, ids_q, ids_k, m, l,
                                 dstat, batch, heads, sq, sk, head_dim, causal, scale, drop_p, seed, nullptr, nullptr, 0, (double)batch * sq * sk, stream);
+}
+
+extern "C" int emdr2_attention_bwd_splitkv(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
+                                           const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, const void *o, const void *dout, void *dq, int64_t dq_sb,
+                                           int64_t dq_ss, void *dk, void *dv, int64_t dkv_sb, int64_t dkv_ss, const int64_t *ids_q, const int64_t *ids_k,
+                                           const int32_t *cu_k, int64_t pairs, const float *m, const float *l, float *dstat,
+                                           int batch, int heads, int sq, int max_sk, int head_dim, int causal, float scale, float drop_p, uint32_t seed,
+                                           int ksplit, void *ws, size_t ws_bytes, void *stream)
+{
+    return attention_bwd_launch(q, q_sb, q_ss, q_sn, k, k_sb, k_ss, k_sn, v, v_sb, v_ss, v_sn, o, dout, dq, dq_sb, dq_ss, dk, dv, dkv_sb, dkv_ss, ids_q, ids_k, m, l,
+                                dstat, batch, heads, sq, max_sk, head_dim, causal, scale, drop_p, seed, nullptr, cu_k, 0, (double)pairs, stream, ksplit, ws, ws_bytes);
 }
 
 extern "C" int emdr2_attention_varlen_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,

@@ -822,6 +822,22 @@ def _attn_side(x, info):
     return info, None, x.stride(0), x.stride(1), x.stride(2), x.shape[0], x.shape[1]
 
 
+_SPLITKV_PLANS = {}
+
+
+def _splitkv_plan(batch, heads, sq, sk):
+    """(ksplit, forward workspace bytes, backward workspace bytes) of a fused attention launch with dense queries [batch, sq] over up to sk
+    keys per sequence (include/emdr2_ops.h: emdr2_attention_splitkv_plan); ksplit 1 = the launch fills the chip by itself."""
+    key = (batch, heads, sq, sk)
+    plan = _SPLITKV_PLANS.get(key)
+    if plan is None:
+        import ctypes
+        ks, fb, bb = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+        _native.check(_lib().emdr2_attention_splitkv_plan(batch, heads, sq, sk, ctypes.byref(ks), ctypes.byref(fb), ctypes.byref(bb)), "attention_splitkv_plan")
+        plan = _SPLITKV_PLANS[key] = (ks.value, fb.value, bb.value)
+    return plan
+
+
 class AttentionCoreFn(torch.autograd.Function):
     """dropout(softmax(mask(Q K^T / sqrt(hn)))) V for all heads (transformer.py:283-381).
     Inputs are the projection outputs themselves: self-attention passes `qsrc` = the packed [b, s, 3, np, hn] QKV tensor (kvsrc None),
@@ -855,6 +871,7 @@ class AttentionCoreFn(torch.autograd.Function):
         if stashed is not None:                                                           # the layer's re-run: reuse the first run's output
             ctxo, m, l = stashed
             ctx.save_for_backward(qsrc, kvsrc, m, l, ctxo)
+            ctx.ksplit = _splitkv_plan(b, heads, sq, sk)[0] if (hn == 64 and not pq and sk <= 65536 and (pk or sk % 32 == 0)) else 1
             return ctxo
         m = torch.empty((heads, ids_q.rows) if pq else (b, heads, sq), dtype=torch.float32, device=dev)
         l = torch.empty_like(m)
@@ -862,7 +879,17 @@ class AttentionCoreFn(torch.autograd.Function):
         fused = hn == 64 and sk <= 65536 and (pk or sk % 32 == 0)
         if (pq or pk) and not fused:
             raise ValueError("packed attention operands need head dim 64 (the fused kernels)")
-        if pq or pk:
+        # few dense queries over very many keys (the FiD decoder's cross-attention, cached decoding steps): keys dealt to several workgroups
+        ksplit, ws_f, _ = _splitkv_plan(b, heads, sq, sk) if (fused and not pq) else (1, 0, 0)
+        ctx.ksplit = ksplit
+        if ksplit > 1:
+            ws = torch.empty(ws_f, dtype=torch.uint8, device=dev)
+            pairs = sq * ids_k.total if pk else b * sq * sk
+            _native.check(_lib().emdr2_attention_fwd_splitkv(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,
+                                                             ctxo.data_ptr(), iq.data_ptr(), ik.data_ptr(), _ptr(ck), int(pairs), b, heads, sq, sk, hn,
+                                                             int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), ksplit,
+                                                             ws.data_ptr(), ws_f, _sp()), "attention_fwd_splitkv")
+        elif pq or pk:
             pairs = ids_q.pairs if (pq and ids_k is ids_q) else (sq * ids_k.total if not pq else 0)
             _native.check(_lib().emdr2_attention_varlen_fwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,
                                                             ctxo.data_ptr(), iq.data_ptr(), ik.data_ptr(), _ptr(cq), _ptr(ck), ids_q.rows if pq else 0,
@@ -916,6 +943,18 @@ class AttentionCoreFn(torch.autograd.Function):
         # scratch of the fused kernels: four per-query statistics (exp2 offset, D = rowsum(dout * o), dropout row hash, real-token flag) the dq
         # kernel leaves for the dk / dv kernel (include/emdr2_ops.h); the unfused path below uses the first [b, heads, sq] as D
         D = torch.empty((4,) + tuple(m.shape), dtype=torch.float32, device=dev)
+        if getattr(ctx, "ksplit", 1) > 1:
+            _, _, ws_b = _splitkv_plan(b, heads, sq, sk)
+            ws = torch.empty(ws_b, dtype=torch.uint8, device=dev)
+            pairs = sq * ids_k.total if pk else b * sq * sk
+            _native.check(lib.emdr2_attention_bwd_splitkv(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,
+                                                          ctxo.data_ptr(), dctx.data_ptr(), dq.data_ptr(), dq_sb, dq_ss, dk.data_ptr(), dv.data_ptr(), dkv_sb,
+                                                          dkv_ss, iq.data_ptr(), ik.data_ptr(), _ptr(ck), int(pairs), m.data_ptr(), l.data_ptr(), D.data_ptr(),
+                                                          b, heads, sq, sk, hn, causal, scale, ctx.drop_p, ctx.seed, ctx.ksplit, ws.data_ptr(), ws_b, _sp()),
+                          "attention_bwd_splitkv")
+            if pk and dkvsrc is not None:
+                ids_k.zero_tail(dkvsrc)
+            return dqsrc, dkvsrc, None, None, None, None, None, None
         if pq or pk:
             pairs = ids_q.pairs if (pq and ids_k is ids_q) else (sq * ids_k.total if not pq else 0)
             _native.check(lib.emdr2_attention_varlen_bwd(q.data_ptr(), q_sb, q_ss, q_sn, k.data_ptr(), k_sb, k_ss, k_sn, v.data_ptr(), v_sb, v_ss, v_sn,

@@ -202,10 +202,62 @@ def test_cross_attention_over_packed_keys_equals_dense(B, Kk, S, L, heads):
     kv_p = K.pack_rows(kv.reshape(B * Kk, S, -1), seqs).reshape(seqs.rows, 2, heads, 64)
     out_p = K.attention_core(q, kv_p, dec_t, seqs.grouped(Kk), False)
     dreal = dec_t != 0
-    assert _rel(out_p[dreal], out_d[dreal]) < 1e-5
+    # r05: launches with few queries and thousands of keys deal their key blocks to several workgroups (emdr2_attention_fwd_splitkv), and the
+    # packed / dense layouts cut their key ranges at different places: the fp32 partial sums meet in another order, a bf16 output may move by
+    # one step (largest shape); smaller shapes do not split and agree to fp32 round-off
+    assert _rel(out_p[dreal], out_d[dreal]) < (8e-3 if Kk * S > 4096 else 1e-5)
+    assert float((out_p[dreal].float() - out_d[dreal].float()).abs().mean() / out_d[dreal].float().abs().mean()) < 1e-3
     (out_p.float() * w).sum().backward()
     assert _rel(q.grad[dreal], gq[dreal]) < 2e-3
     assert _rel(kv.grad[real], gkv[real]) < 2e-3 and float(kv.grad[~real].abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("drop_p", [0.0, 0.1])
+def test_split_key_launches_equal_the_unsplit_launch(drop_p):
+    """r05: few dense queries over very many keys -- the FiD cross-attention of a group of questions, cached decoding steps -- deal the key
+    blocks of a (question, head) to several workgroups and fold fp32 partials (emdr2_attention_fwd_splitkv / _bwd_splitkv).  Same outputs,
+    same statistics, same gradients as ONE workgroup walking all keys, up to the order of fp32 additions: packed grouped keys with one
+    question that has almost no keys (most of its splits are empty), dense keys, padded decoder positions (uniform rows), dropout."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(3)
+    B, Kk, S, L, heads = 3, 50, 512, 32, 2
+    ids, _ = _ragged_ids(rng, B * Kk, S, 500, lo=S // 4)
+    ids[Kk:2 * Kk, 1:] = 0                                               # question 1: one token per passage, 50 keys in all
+    ids_t = torch.from_numpy(ids).cuda()
+    dec, _ = _ragged_ids(rng, B, L, 500, lo=2)
+    dec_t = torch.from_numpy(dec).cuda()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    q = torch.randn((B, L, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    seqs = K.PackedSeqs(ids_t)
+    kv_p = torch.randn((seqs.rows, 2, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    kv_d = torch.randn((B, 25600, 2, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    ids_d = torch.randint(1, 100, (B, 25600), generator=g, device="cuda")
+    ids_d[0, 20000:] = 0; ids_d[2, 37:] = 0
+    w = torch.randn((B, L, heads, 64), generator=g, device="cuda")
+
+    def run(kv, ids_k, force_unsplit):
+        K._SPLITKV_PLANS.clear()
+        sk = ids_k.max_len if isinstance(ids_k, K.PackedSeqs) else ids_k.shape[1]
+        plan = K._splitkv_plan(B, heads, L, sk)
+        assert plan[0] > 1, plan                                         # this shape does split on the device
+        if force_unsplit:
+            K._SPLITKV_PLANS[(B, heads, L, sk)] = (1, 0, 0)
+        q.grad = kv.grad = None
+        out = K.attention_core(q, kv, dec_t, ids_k, False, drop_p=drop_p, seed=77)
+        (out.float() * w).sum().backward()
+        K._SPLITKV_PLANS.clear()
+        return out.detach().clone(), q.grad.clone(), kv.grad.clone()
+
+    for kv, ids_k in ((kv_p, seqs.grouped(Kk)), (kv_d, ids_d)):
+        o1, dq1, dkv1 = run(kv, ids_k, True)
+        o2, dq2, dkv2 = run(kv, ids_k, False)
+        # (bf16 outputs: a different order of the fp32 additions may move a value by one bf16 step)
+        assert _rel(o2, o1) < 8e-3 and bool(torch.isfinite(o2.float()).all()), _rel(o2, o1)
+        assert float((o2.float() - o1.float()).abs().mean() / o1.float().abs().mean()) < 1e-3
+        assert _rel(dq2, dq1) < 1e-2, _rel(dq2, dq1)
+        assert _rel(dkv2, dkv1) < 1e-2, _rel(dkv2, dkv1)                 # (dk / dv see the statistics the split forward left)
+        o3, dq3, dkv3 = run(kv, ids_k, False)                            # partials are folded in split order: bit-reproducible
+        assert torch.equal(o3, o2) and torch.equal(dq3, dq2)
 
 
 def test_packed_attention_dropout_mask_exact_at_block_boundaries():
