@@ -60,6 +60,7 @@ def parse():
                     help="skip the `e2e_k100` object: BASELINE configs[4] (top-k 100 + continuous re-embedding on a side stream) at its per-rank "
                          "shape -- the N/8-row index shard of an 8-GPU run -- timed with and without the refresher")
     ap.add_argument("--k100-steps", type=int, default=2)
+    ap.add_argument("--no-clustered", action="store_true", help="skip the `clustered` object: the same search over a topic-contiguous, anisotropic corpus")
     import bench_e2e
     bench_e2e.add_args(ap)
     return ap.parse_args()
@@ -74,6 +75,106 @@ def synth_rows(lo, hi, seed=1234):
         block = torch.randn((GEN_CHUNK, DIM), generator=g, device="cuda", dtype=torch.float32).to(torch.float16)
         a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
         yield block[a - c * GEN_CHUNK: b - c * GEN_CHUNK]
+
+
+TOPIC_ROWS = 32
+
+
+def _topic_block(chunk, seed):
+    """(centers fp32 [GEN_CHUNK / 32, DIM], norm scales [GEN_CHUNK / 32]) of the topics of generator chunk `chunk` of the clustered corpus."""
+    g = torch.Generator(device="cuda").manual_seed(seed * 1_000_003 + 7_000_000 + chunk)
+    nt = GEN_CHUNK // TOPIC_ROWS
+    centers = torch.randn((nt, DIM), generator=g, device="cuda", dtype=torch.float32)
+    scales = torch.exp(0.25 * torch.randn((nt,), generator=g, device="cuda", dtype=torch.float32))
+    return centers, scales
+
+
+def synth_rows_clustered(lo, hi, seed=1234, alpha=0.8):
+    """Rows [lo, hi) of the CLUSTERED synthetic index: the opposite of i.i.d. rows in the three respects that matter to
+    a threshold filter walking the rows in order -- (1) topic-contiguous: every 32 consecutive rows share a topic centre (cosine 0.64 to it:
+    consecutive passages of one article), (2) anisotropic: a topic's rows carry a log-normal norm factor (sigma 0.25), (3) queries
+    (`clustered_queries`) sit near topics at the very END of the row order, so the rows that matter arrive after every threshold was set on
+    unrelated ones.  Chunk-keyed like `synth_rows`: a row does not depend on the sharding."""
+    c0, c1 = lo // GEN_CHUNK, (hi + GEN_CHUNK - 1) // GEN_CHUNK
+    beta = (1.0 - alpha * alpha) ** 0.5
+    for c in range(c0, c1):
+        centers, scales = _topic_block(c, seed)
+        g = torch.Generator(device="cuda").manual_seed(seed * 1_000_003 + c)
+        block = torch.randn((GEN_CHUNK, DIM), generator=g, device="cuda", dtype=torch.float32)
+        block = block.view(-1, TOPIC_ROWS, DIM).mul_(beta).add_(alpha * centers[:, None, :]).mul_(scales[:, None, None]).view(GEN_CHUNK, DIM).to(torch.float16)
+        a, b = max(lo, c * GEN_CHUNK), min(hi, (c + 1) * GEN_CHUNK)
+        yield block[a - c * GEN_CHUNK: b - c * GEN_CHUNK]
+
+
+def clustered_queries(n_rows, nq, seed=1234, per_topic=8):
+    """nq fp16 queries near nq / per_topic distinct topics taken from the last 2 % of the rows (8 questions about each late article)."""
+    g = torch.Generator(device="cuda").manual_seed(seed + 99)
+    n_topics = max(1, nq // per_topic)
+    first = max(0, int(n_rows * 0.98) // TOPIC_ROWS)
+    last = max(first + 1, (n_rows - 1) // TOPIC_ROWS)
+    topics = first + torch.randperm(max(last - first, 1), generator=g, device="cuda")[:n_topics]
+    topics = topics.repeat_interleave(per_topic)[:nq]
+    if topics.numel() < nq:
+        topics = torch.cat([topics, topics[:nq - topics.numel()]])
+    out = torch.empty((nq, DIM), dtype=torch.float32, device="cuda")
+    per_chunk = GEN_CHUNK // TOPIC_ROWS
+    for c in torch.unique(topics // per_chunk).tolist():
+        centers, _ = _topic_block(int(c), seed)
+        m = (topics // per_chunk) == c
+        out[m] = centers[(topics[m] % per_chunk)]
+    out += 0.3 * torch.randn((nq, DIM), generator=g, device="cuda", dtype=torch.float32)
+    return out.to(torch.float16)
+
+
+def clustered_leg(args, rank, world, steps=5):
+    """The search over the clustered corpus (same size, same kernels, same operator): queries/s, how many queries the fast path could not
+    prove (they take the all-exact path inside the operator), the time of one all-exact pass (8 queries over this rank's rows), and the
+    bound on a search they imply.  Rank-local timing; N > 1: every rank searches its shard, exchange included."""
+    from emdr2_amd.data.emdr2_index import DistributedBruteForceIndex, shard_bounds
+    index = DistributedBruteForceIndex(embed_size=DIM, embed_data=None, use_gpu=True)
+    lo, hi = shard_bounds(args.rows, world)[rank]
+    index.num_rows = args.rows
+    index.shard = index._make_shard(DIM, hi - lo, lo)
+    for block in synth_rows_clustered(lo, hi):
+        index.shard.append_rows(block)
+    index.shard.set_ids(torch.arange(lo + 1, hi + 1, dtype=torch.int32, device="cuda"))
+    q = clustered_queries(args.rows, args.queries)
+    k = args.topk
+    for _ in range(2):
+        index.search_mips_index(q, k)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        index.search_mips_index(q, k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    d, i, r, f = index.shard.search(q, k, exact_fallback=False)
+    flagged = int((f != 0).sum().item())
+    overflow = int(((f & 2) != 0).sum().item())
+    sel = torch.arange(8, dtype=torch.int32, device="cuda")
+    d2, i2, r2, f2 = d.clone(), i.clone(), r.clone(), f.clone()
+    index.shard.search_exact(q, sel, k, d2, i2, r2, f2)                   # (also the correctness net's own check below)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    index.shard.search_exact(q, sel, k, d2, i2, r2, f2)
+    torch.cuda.synchronize()
+    exact_ms = (time.perf_counter() - t0) * 1e3
+    ok = f[:8].abs().sum().item() != 0 or (torch.equal(d[:8].view(torch.int16), d2[:8].view(torch.int16)) and torch.equal(i[:8], i2[:8]))
+    # where the top-50 of these queries live: the share found in the last 2 % of the rows
+    late = float((r >= int(args.rows * 0.98)).float().mean().item())
+    passes = (args.queries + 7) // 8
+    out = {"data": "clustered: 32-row topic runs (cosine 0.64 to the topic centre), log-normal topic norms (sigma 0.25), %d queries near %d topics of the "
+                   "last 2 %% of the rows" % (args.queries, max(1, args.queries // 8)),
+           "queries_per_s": args.queries / (ms * 1e-3), "ms_per_search": ms, "unproven_queries": flagged, "candidate_overflow_queries": overflow,
+           "share_of_topk_from_the_last_2pct_rows": late, "fast_path_equals_exact_path_on_8_queries": bool(ok),
+           "exact_pass_ms_per_8_queries": exact_ms,
+           "worst_case_bound_ms": ms + passes * exact_ms,
+           "worst_case_note": "a query the fast path cannot prove costs its share of an all-exact pass (integer arithmetic over every row, 8 queries "
+                              "per pass): at most %d passes for %d queries on top of the fast path" % (passes, args.queries)}
+    del index
+    return out
 
 
 def cpu_baseline(args, queries_cpu):
@@ -252,6 +353,16 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, queries.cpu().numpy())
     else:
         result = None
+
+    if not args.no_clustered:
+        try:
+            cl = clustered_leg(args, rank, world)
+        except Exception as exc:
+            cl = {"error": "%s: %s" % (type(exc).__name__, exc)}
+        import gc
+        gc.collect(); torch.cuda.empty_cache()
+        if rank == 0:
+            result["clustered"] = cl
 
     # ---- second half of the metric: the end-to-end training step over the same resident index ---------------------------------------
     if not args.no_e2e:

@@ -62,6 +62,7 @@ __device__ __forceinline__ float half_sum(float x)
 }
 
 #define KB 64   // keys per block
+#define KSPLIT_BLOCKS 32   // key blocks (2,048 keys) per workgroup of a split-key launch: a sequence's ranges depend on ITS key count only
 #define QW 32   // queries per wave
 #define NW 4    // waves per workgroup
 #define QB (NW * QW)  // queries per workgroup
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     const char *v_src = p.v + (v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
     const int nblk_all = (sk + KB - 1) / KB;
     // this workgroup's key blocks [blk_lo, nblk): all of them, or its share of a split launch (possibly none: more splits than blocks)
-    const int blk_lo = p.ksplit > 1 ? (int)((long long)nblk_all * split / p.ksplit) : 0;
-    const int nblk = p.ksplit > 1 ? (int)((long long)nblk_all * (split + 1) / p.ksplit) : nblk_all;
+    const int blk_lo = p.ksplit > 1 ? min(split * KSPLIT_BLOCKS, nblk_all) : 0;
+    const int nblk = p.ksplit > 1 ? min((split + 1) * KSPLIT_BLOCKS, nblk_all) : nblk_all;
     auto issue = [&](int blk, int stage) {                                     // dense: sk % 32 == 0 (checked on the host); packed: any sk
         char *sb = smem + stage * 16384;
 #pragma unroll
@@ -259,7 +260,10 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
             // exp2(s - m) <= 256: nothing for fp32 sums or bf16 probabilities (same relative precision), and O / l is unchanged
             // mathematically; (m, l) stay consistent for the backward, which only ever uses m + log2 l.
             if (__builtin_amdgcn_ballot_w64(bmax > mrun + 8.f) != 0ull) {
-                const float mnew = fmaxf(mrun, bmax);
+                // r05: the reference point is a WHOLE number of binades: exp2(s - m) then has the same mantissa whatever m a walk over
+                // the keys arrives at, so the bf16 probabilities that enter P V -- and with them O up to the order of fp32 additions --
+                // do not depend on where a walk starts: key-split launches, packed vs dense layouts and groups of any size agree
+                const float mnew = __builtin_ceilf(fmaxf(mrun, bmax));
                 const float alpha = __builtin_amdgcn_exp2f(mrun - mnew);
                 lrun *= alpha;
 #pragma unroll
@@ -341,16 +345,15 @@ __global__ void __launch_bounds__(256) attention_combine_kernel(AttnParams p, fl
 
 } // namespace
 
-// how many ways to split the keys of a launch with `wgs` (batch x heads x query blocks) workgroups and up to `nblk` key blocks each: only
-// when the launch cannot fill the chip by itself (4 workgroups per CU resident) and the key walk is long
-static int attention_ksplit(long long wgs, int nblk, int cus)
+// Whether (and how many ways) a launch splits its keys: ONE query block (<= 128 dense queries) over sequences of 4,096 keys or more, in
+// ranges of KSPLIT_BLOCKS blocks.  A function of the launch's query / key EXTENTS only, never of the batch: the same question gives the same
+// bits whether it runs alone, in a group of 8 or in a batch of 64 (question micro-batching relies on it), and short-key launches -- every
+// shape the bf16-faithful oracle walks step by step -- never split.
+static int attention_ksplit(int max_sq, int max_sk)
 {
-    if (wgs <= 0 || wgs * 2 > 4ll * cus || nblk < 16) return 1;
-    long long want = (6ll * cus + wgs - 1) / wgs;                                 // ~1.5 rounds of resident workgroups
-    const long long most = nblk / 4;                                              // >= 4 key blocks per workgroup
-    if (want > most) want = most;
-    if (want > 64) want = 64;
-    return want < 2 ? 1 : (int)want;
+    if (max_sq > QB || max_sk < 4096) return 1;
+    const int nblk = (max_sk + KB - 1) / KB;
+    return (nblk + KSPLIT_BLOCKS - 1) / KSPLIT_BLOCKS;                            // <= 32 (sk <= 65,536)
 }
 
 static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
@@ -359,7 +362,7 @@ static int attention_fwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
                                 int64_t total_q, double pairs, void *stream, int ksplit = 1, void *ws = nullptr, size_t ws_bytes = 0)
 {
     if (!q || !k || !v || !o || !ids_q || !ids_k || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15)))) return -1;
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15) || ksplit != attention_ksplit(sq, sk)))) return -1;
     if (head_dim != 64 || sk < 1 || sk > 65536 || (q_ss & 7) || (k_ss & 7) || (q_sn & 7) || (k_sn & 7) || (q_sb & 7) || (k_sb & 7) || (v_sb & 7) || (v_ss & 7) || (v_sn & 7)) return -4;
     if (!cu_k && (sk < 32 || (sk & 31))) return -4;                                  // dense keys: whole 32-key steps (padded queries average over exactly sk keys)
     if (cu_q && total_q < 1) return -1;
@@ -403,11 +406,7 @@ extern "C" int emdr2_attention_fwd(const void *q, int64_t q_sb, int64_t q_ss, in
 extern "C" int emdr2_attention_splitkv_plan(int batch, int heads, int max_sq, int max_sk, int *ksplit, size_t *fwd_bytes, size_t *bwd_bytes)
 {
     if (!ksplit || !fwd_bytes || !bwd_bytes || batch < 1 || heads < 1 || max_sq < 1 || max_sk < 1) return -1;
-    int dev = 0, cus = 256;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) cus = prop.multiProcessorCount;
-    const long long wgs = (long long)batch * heads * ((max_sq + QB - 1) / QB);
-    const int ks = attention_ksplit(wgs, (max_sk + KB - 1) / KB, cus);
+    const int ks = attention_ksplit(max_sq, max_sk);
     const size_t stat_n = (size_t)batch * heads * max_sq;
     *ksplit = ks;
     *fwd_bytes = ks > 1 ? (size_t)ks * stat_n * 66 * sizeof(float) : 0;

@@ -81,6 +81,7 @@ __device__ __forceinline__ SeqExtent seq_extent(const BwdParams &p, int b, int n
 // ============================================================ dq =====================================================================
 // Like the forward (attention.hip): VALU-bound, so workgroups are FOUR waves (128 queries) at <= 168 VGPRs -- three per CU, each on its own
 // barrier -- and a staged 64-key block is consumed as two 32-key steps (one S / dP accumulator pair live); DROP / CAUSAL are compile-time.
+#define KSPLIT_BLOCKS 32       // key blocks per workgroup of a split-key launch (attention.hip)
 #define BNW 4
 #define KNW 4                  // waves (32 keys each) per workgroup of the dK / dV kernel
 template <bool DROP, bool CAUSAL>
@@ -108,8 +109,8 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     const char *k_src = p.k + (ex.k_off + (long long)n * p.k_sn) * 2 + pslot * 16;
     const char *v_src = p.v + (ex.v_off + (long long)n * p.v_sn) * 2 + pslot * 16;
     const int nblk_all = (sk + 63) / 64;
-    const int blk_lo = p.ksplit > 1 ? (int)((long long)nblk_all * split / p.ksplit) : 0;             // this workgroup's key blocks [blk_lo, nblk)
-    const int nblk = p.ksplit > 1 ? (int)((long long)nblk_all * (split + 1) / p.ksplit) : nblk_all;
+    const int blk_lo = p.ksplit > 1 ? min(split * KSPLIT_BLOCKS, nblk_all) : 0;                      // this workgroup's key blocks [blk_lo, nblk)
+    const int nblk = p.ksplit > 1 ? min((split + 1) * KSPLIT_BLOCKS, nblk_all) : nblk_all;
     auto issue = [&](int blk, int stage) {
         char *sb = smem + stage * 16384;
 #pragma unroll
@@ -531,7 +532,7 @@ static int attention_bwd_launch(const void *q, int64_t q_sb, int64_t q_ss, int64
                                 int64_t total_q, double pairs, void *stream, int ksplit = 1, void *ws = nullptr, size_t ws_bytes = 0)
 {
     if (!q || !k || !v || !o || !dout || !dq || !dk || !dv || !ids_q || !ids_k || !m || !l || !dstat || batch < 1 || heads < 1 || sq < 1) return -1;
-    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15)))) return -1;
+    if (ksplit < 1 || ksplit > 64 || (ksplit > 1 && (cu_q || !ws || ((uintptr_t)ws & 15) || sq > BNW * 32 || ksplit != ((sk + 63) / 64 + KSPLIT_BLOCKS - 1) / KSPLIT_BLOCKS))) return -1;
     if (head_dim != 64 || sk < 1 || sk > 65536) return -4;
     if (!cu_k && (sk < 32 || (sk & 31))) return -4;
     if (cu_q && total_q < 1) return -1;

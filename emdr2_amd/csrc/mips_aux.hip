@@ -224,7 +224,7 @@ __device__ __forceinline__ void select_block(SelectShared &sh, uint2 *cand_all, 
 #pragma unroll
     for (int x = 0; x < 8; ++x) {
         unsigned m = cand8 ? count8[x * 512 + q] : 0u;
-        if (m > SUBCAP) { if (tid == 0) atomicOr(&flags[q], 2u); m = SUBCAP; }          // a sub-list overflowed: candidates were lost -> exact fallback
+        if (m > SUBCAP) m = SUBCAP;                                     // (a full sub-list spilled its later survivors into the main list: mips_scan8.hip s8_append)
         any_sub |= m != 0;
         n += m;
         cv.sub_end[x] = n;

@@ -49,8 +49,14 @@ struct Scan8Params {
 __device__ __forceinline__ void s8_append(const ScanParams &p, unsigned xcc, unsigned q, unsigned score_bits, unsigned row)
 {
     const unsigned slot = __hip_atomic_fetch_add(&p.count8[xcc * 512 + q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (slot < SUBCAP) p.cand8[((size_t)q * 8 + xcc) * SUBCAP + slot] = make_uint2(score_bits, row);
-    // (past the end: the count keeps growing and the select flags the query for the exact fallback)
+    if (slot < SUBCAP) { p.cand8[((size_t)q * 8 + xcc) * SUBCAP + slot] = make_uint2(score_bits, row); return; }
+    // r05: a full sub-list SPILLS into the query's main list (CAPQ entries, shared by all XCDs: agent-scope atomic) instead of dropping the
+    // survivor.  An XCD owns a CONTIGUOUS range of the row sequence, so in an index whose neighbouring rows are similar (consecutive passages
+    // of one article) a query's survivors of a segment pile up in ONE sub-list; before, 1,024 of them sent the query to the all-exact
+    // path (a host sync + an integer pass over every row) although the other seven sub-lists and the 16,384-entry main list stood empty.
+    // The count keeps growing past SUBCAP (the select clamps it); only a full MAIN list loses candidates and flags the query.
+    const unsigned s2 = __hip_atomic_fetch_add(&p.count[q], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (s2 < p.capq) p.cand[(size_t)q * p.capq + s2] = make_uint2(score_bits, row);
 }
 
 // queue -> candidate sub-lists; cnt[w] = entries in wave w's region (all 512 threads take part: thread t drains region t >> 6)

@@ -12,6 +12,7 @@
 // attention kernels take cu (csrc/attention.hip); the kernels here build the layout and move rows between the two forms.
 #include "../../include/emdr2_ops.h"
 #include <hip/hip_runtime.h>
+#include <mutex>
 #include <stdint.h>
 
 namespace {
@@ -121,10 +122,22 @@ extern "C" int emdr2_seq_lengths(const int64_t *ids, int n, int S, int32_t *cu, 
     if (!ids || !cu || !totals || n < 1 || S < 1) return -1;
     if (n > 38000) return -4;                                                    // the lengths live in LDS: 152 of the 160 KB (B = 256 at top-k 100 is 25,600)
     if (n > 16000) {                                                             // past the 64 KB a kernel gets without asking
-        static bool attr_done = false;
-        if (!attr_done) {
-            if (hipFuncSetAttribute((const void *)seq_lengths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 38000 * (int)sizeof(int)) != hipSuccess) return -3;
-            attr_done = true;
+        // the attribute belongs to (function, device): one flag per device ordinal, set under a lock (callers may be threads of several devices);
+        // a device whose opt-in LDS limit is below the request (not gfx950) is an unsupported shape, not a runtime error
+        static std::mutex attr_lock;
+        static bool attr_done[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return -3;
+        std::lock_guard<std::mutex> guard(attr_lock);
+        if (!attr_done[dev]) {
+            int optin = 0;
+            if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) optin = 0;
+            if (optin > 0 && optin < 38000 * (int)sizeof(int)) return -4;
+            if (hipFuncSetAttribute((const void *)seq_lengths_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 38000 * (int)sizeof(int)) != hipSuccess) {
+                (void)hipGetLastError();
+                return -4;
+            }
+            attr_done[dev] = true;
         }
     }
     hipLaunchKernelGGL(seq_len_kernel, dim3((unsigned)(n + 15) / 16), dim3(1024), 0, (hipStream_t)stream, (const long long *)ids, n, S, (int *)cu);

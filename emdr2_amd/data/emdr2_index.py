@@ -110,10 +110,31 @@ class OpenRetreivalDataStore(object):
         ids = np.fromiter(self.embed_data.keys(), dtype=np.int64, count=n)
         if n and (ids.min() < -2 ** 31 or ids.max() >= 2 ** 31):
             raise ValueError("doc ids must fit int32 (reference returns int32 ids, emdr2_index.py:298)")
-        rows = np.empty((n, len(next(iter(self.embed_data.values()))) if n else 0), dtype=np.float16)
-        for i, v in enumerate(self.embed_data.values()):
-            rows[i] = v
+        dim = len(next(iter(self.embed_data.values()))) if n else 0
+        rows = np.empty((n, dim), dtype=np.float16)
+        for lo, block in self.iter_row_blocks():
+            rows[lo:lo + block.shape[0]] = block
         return ids.astype(np.int32), rows
+
+    def iter_row_blocks(self, block_rows=1 << 18):
+        """(first row, fp16 [<= block_rows, D]) blocks in dict order: the values are gathered by numpy 262,144 at a time (one C loop per
+        block) instead of one Python assignment per row -- 21M of them at the full index."""
+        import itertools
+        it = iter(self.embed_data.values())
+        lo = 0
+        while True:
+            chunk = list(itertools.islice(it, block_rows))
+            if not chunk:
+                return
+            block = np.asarray(chunk, dtype=np.float16)
+            if block.ndim != 2:
+                raise ValueError("embedding rows of unequal length")
+            yield lo, block
+            lo += block.shape[0]
+
+    def flat_path(self):
+        """Where the flat twin of `embedding_path` lives (FlatEmbeddingFile; written by `ensure_flat_embedding_file`)."""
+        return os.path.splitext(self.embedding_path)[0] + '.flat'
 
 
 # ---- flat evidence-embedding file (SURVEY 8f-2) --------------------------------------------------------------------------------
@@ -156,14 +177,62 @@ class FlatEmbeddingFile(object):
 
     @classmethod
     def from_store(cls, store, path):
-        ids, rows = store.to_arrays()
-        cls.write(path, ids, rows)
+        """Stream the store into `path` block by block (never a second dense copy of the matrix in host memory), atomically (tmp + rename)."""
+        import struct
+        n = len(store.embed_data)
+        ids = np.fromiter(store.embed_data.keys(), dtype=np.int64, count=n)
+        if n and (ids.min() < -2 ** 31 or ids.max() >= 2 ** 31):
+            raise ValueError("doc ids must fit int32 (reference returns int32 ids, emdr2_index.py:298)")
+        dim = len(next(iter(store.embed_data.values()))) if n else 0
+        tmp = path + '.tmp.%d' % os.getpid()
+        with open(tmp, 'wb') as f:
+            f.write(FLAT_MAGIC)
+            f.write(struct.pack('<IIQ', 1, dim, n))
+            f.write(ids.astype(np.int32).tobytes())
+            f.write(b'\0' * ((-f.tell()) % 4096))
+            for _, block in store.iter_row_blocks():
+                if block.shape[1] != dim:
+                    raise ValueError("embedding rows of unequal length")
+                f.write(np.ascontiguousarray(block).tobytes())
+        os.replace(tmp, path)
         return cls(path)
 
     def to_store(self, embedding_path, rank=0):
         store = OpenRetreivalDataStore(embedding_path, load_from_path=False, rank=rank)
         store.add_block_data(self.ids.tolist(), np.asarray(self.rows))
         return store
+
+
+def ensure_flat_embedding_file(embedding_path, process_group=None, log=None):
+    """The flat twin of the `--embedding-path` pickle, converted ONCE per (re)load by the first rank and memory-mapped by all.
+
+    The reference unpickles the 32 GB store on the node-first rank only (emdr2_model.py:414-423) and that rank uploads every device's chunk.
+    With one process per GPU every rank needs ITS rows; letting each of 8 ranks unpickle 21M small arrays and densify them costs 8 x (40 + 32)
+    GB of host memory and minutes, at start-up and at every `update_index()`.  Here rank 0 of the group converts the pickle to
+    `<path minus extension>.flat` if that file is missing or older than the pickle, everybody meets at a barrier, and each rank then maps the
+    file and touches only its own row range (`DistributedBruteForceIndex.add_flat_file`).  Returns the flat file's path."""
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    rank = torch.distributed.get_rank(process_group) if dist_on else 0
+    flat = os.path.splitext(embedding_path)[0] + '.flat'
+    err = None
+    if rank == 0:
+        try:
+            stale = (not os.path.exists(flat)) or os.path.getmtime(flat) < os.path.getmtime(embedding_path)
+            if stale:
+                store = OpenRetreivalDataStore(embedding_path, load_from_path=True, rank=0)
+                FlatEmbeddingFile.from_store(store, flat)
+                if log:
+                    log("converted %s (%d embeddings) to %s" % (embedding_path, len(store.embed_data), flat))
+                store.clear()
+        except Exception as exc:                                   # the peers are waiting at the barrier: meet them first, then raise
+            err = exc
+    if dist_on:
+        torch.distributed.barrier(process_group)
+    if err is not None:
+        raise err
+    if not os.path.exists(flat):
+        raise RuntimeError("flat embedding file %s was not produced by rank 0" % flat)
+    return flat
 
 
 def shard_bounds(num_rows, world_size):
@@ -195,14 +264,18 @@ class HipIndexShard(object):
     def append_rows(self, rows):
         """rows: fp16 [n, dim] (numpy or torch, host or device); appended at the next free local row."""
         if isinstance(rows, np.ndarray):
-            rows = torch.from_numpy(np.ascontiguousarray(rows))
-        if rows.dtype != torch.float16 or rows.dim() != 2 or rows.shape[1] != self.dim:
+            if rows.dtype != np.float16 or rows.ndim != 2 or rows.shape[1] != self.dim:
+                raise ValueError("rows must be float16 [n, %d]" % self.dim)
+        elif rows.dtype != torch.float16 or rows.dim() != 2 or rows.shape[1] != self.dim:
             raise ValueError("rows must be float16 [n, %d]" % self.dim)
         n = rows.shape[0]
         if self._filled + n > self.n_rows:
             raise ValueError("shard overflow")
         for lo in range(0, n, _UPLOAD_ROWS):
-            chunk = rows[lo:lo + _UPLOAD_ROWS].to(self.device, non_blocking=False).contiguous()
+            chunk = rows[lo:lo + _UPLOAD_ROWS]
+            if isinstance(chunk, np.ndarray):                      # (a memory map: only this 1.5 GiB piece is ever resident on the host)
+                chunk = torch.from_numpy(np.array(chunk, dtype=np.float16, order='C', copy=True))
+            chunk = chunk.to(self.device, non_blocking=False).contiguous()
             _native.check(self.lib.emdr2_mips_pack_rows(chunk.data_ptr(), chunk.shape[0], self.dim, self._filled,
                                                         self.n_rows, self.tiled.data_ptr(), self.emax_sq.data_ptr(),
                                                         _native.stream_ptr()), "pack_rows")
@@ -466,20 +539,27 @@ class DistributedBruteForceIndex(object):
     # -- reference API -------------------------------------------------------------------------------
     def _set_mips_index(self):
         if self.embed_data is not None:
-            self.add_embed_data(self.embed_data)
+            if not self.embed_data.embed_data and getattr(self.embed_data, "embedding_path", None) and os.path.exists(self.embed_data.embedding_path):
+                # a store that has not been loaded (load_from_path=False): go through the flat twin of its file -- rank 0 converts, every
+                # rank maps its own rows; no rank but the first ever unpickles
+                self.add_flat_file(ensure_flat_embedding_file(self.embed_data.embedding_path, self.process_group))
+            else:
+                self.add_embed_data(self.embed_data)
 
     def reset_index(self):
         self.shard = None
         if self.embed_data is not None:
             embed_data_path = self.embed_data.embedding_path
             del self.embed_data
-            self.embed_data = OpenRetreivalDataStore(embed_data_path)
+            self.embed_data = OpenRetreivalDataStore(embed_data_path, load_from_path=False)      # (loaded through its flat twin below)
         self._set_mips_index()
 
     def update_index(self):
+        """emdr2_index.py:232-238: reload `embedding_path` (a new indexer job has rewritten it).  The store object stays empty: the rows
+        travel pickle -> flat file (rank 0, once) -> each rank's own memory-mapped slice -> HBM."""
         self.shard = None
         if self.embed_data is not None:
-            self.embed_data.load_from_file()
+            self.embed_data.clear()
         self._set_mips_index()
 
     # -- in-HBM refresh of this rank's rows (SURVEY 8e config 5; indexer_emdr2.IndexBuilder.build_into_index) -------------------

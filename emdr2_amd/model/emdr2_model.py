@@ -39,7 +39,10 @@ class PreComputedEvidenceDocsRetriever(object):
         self.precomputed_index_wrapper(embed_data)
 
     def get_evidence_embedding(self, path):
-        self.evidence_embedder_obj = OpenRetreivalDataStore(path, load_from_path=True)
+        # not loaded here: DistributedBruteForceIndex takes an unloaded store through the flat twin of its file (rank 0 converts the pickle
+        # once, every rank maps its own rows; emdr2_index.ensure_flat_embedding_file) -- the reference unpickles on the node-first rank
+        # only (emdr2_model.py:414-423), which one process per GPU would turn into 8 x 70 GB of host memory
+        self.evidence_embedder_obj = OpenRetreivalDataStore(path, load_from_path=False)
 
     def precomputed_index_wrapper(self, embed_data=None):
         if embed_data is None:

@@ -257,8 +257,12 @@ class _PreMask(object):
     """The backward of a bias-dropout-add (y = x + dropout(z)) needs dy o mask as the operand of two GEMMs.  `dy` is produced by the backward of
     the LayerNorm that consumed y, so that launch can write the masked copy on its way (csrc/elementwise.hip: layernorm_bwd768_kernel<true>)
     instead of a dropout launch re-reading dy.  Forward: the bias-dropout-add registers (p, seed) under its output's address (`want`);
-    backward: the LayerNorm backward whose INPUT has that address leaves (address of dx, p, seed) -> masked tensor in the one `slot`; the
-    bias-dropout-add's backward takes it if every part of the key matches and falls back to the dropout kernel otherwise.  One slot: the
+    backward: the LayerNorm backward whose INPUT has that address leaves (dx ITSELF, p, seed) -> masked tensor in the one `slot`; the
+    bias-dropout-add's backward takes it if its dy IS that dx (same storage, same shape, not written since) with the same (p, seed), and
+    falls back to the dropout kernel otherwise.  The slot holds dx -- not just its address -- on purpose: were y ever consumed
+    by a second autograd node, autograd's input buffer could ADD that node's gradient into the dx buffer in place (it does when it holds
+    the only reference to tensor and storage), same address, other values, and the masked copy would be mask(partial dx); with the slot's
+    reference the sum goes to a fresh tensor (another address: no match), and `_version` catches any other in-place write.  One slot: the
     consumer is the next node autograd runs, anything else overwrites or clears it, so at most one extra [tokens, h] tensor is alive."""
 
     def __init__(self):
@@ -272,11 +276,17 @@ class _PreMask(object):
         req = self.want.pop(x2.data_ptr(), None)
         return req if (req is not None and req[2] == x2.numel()) else None
 
+    def offer(self, dx, drop_p, seed, dmask):
+        self.slot = (dx, dx._version, float(drop_p), int(seed), dmask)
+
     def take(self, dy2, drop_p, seed):
         slot, self.slot = self.slot, None
-        if slot is not None and slot[0] == (dy2.data_ptr(), float(drop_p), int(seed)) and slot[1].shape == dy2.shape:
-            self.fused += 1
-            return slot[1]
+        if slot is not None:
+            dx, version, p, sd, dmask = slot
+            if (dx.data_ptr() == dy2.data_ptr() and dx._version == version and dy2._version == version and dx.numel() == dy2.numel()
+                    and (p, sd) == (float(drop_p), int(seed)) and dmask.shape == dy2.shape):
+                self.fused += 1
+                return dmask
         self.unfused += 1
         return None
 
@@ -639,7 +649,7 @@ def _ln_backward(dy2, x2, gamma, beta, mean, rstd, dres):
         rc = _lib().emdr2_layernorm_bwd_mask(dy2.data_ptr(), x2.data_ptr(), gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _ptr(dres), dx.data_ptr(),
                                              dg.data_ptr(), db.data_ptr(), rows, H, dmask.data_ptr(), req[0], req[1], _sp())
         if rc == 0:
-            PREMASK.slot = ((dx.data_ptr(), req[0], req[1]), dmask)
+            PREMASK.offer(dx, req[0], req[1], dmask)
         elif rc != -4:
             _native.check(rc, "layernorm_bwd_mask")
     if rc == -4:

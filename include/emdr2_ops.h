@@ -144,11 +144,13 @@ int emdr2_attention_varlen_bwd(const void *q, int64_t q_sb, int64_t q_ss, int64_
 /* Split-key launches of the same kernels for FEW queries over VERY MANY keys: the FiD decoder's cross-attention (emdr2_model.py:166-183:
  * batch questions x 32 decoder positions over the ~20,000 / 40,000 packed encoder tokens of a question's 50 / 100 passages) and the cached
  * decoding steps of search_strategy.py:185-240.  One workgroup per (batch, head) walking every key block leaves most of the chip idle when
- * batch x heads is a few hundred; here the key blocks of a (batch, head, query block) are dealt to `ksplit` workgroups whose fp32 partials
- * (forward: unnormalised O + (m, l); backward: dQ) go through the caller's workspace and are folded by a small second kernel, in split order
- * (deterministic).  Queries are DENSE [batch, sq] (q_sb / dq_sb strides); cu_k as above or NULL for dense keys.  Same results as the
- * unsplit launch up to the order of fp32 additions.
- *   _plan: ksplit for this shape on the current device (1 = do not split) and the workspace bytes of the two launches (16-byte aligned ws). */
+ * batch x heads is a few hundred; here the key blocks of a (batch, head) are dealt, 32 blocks (2,048 keys) each, to `ksplit` workgroups whose
+ * fp32 partials (forward: unnormalised O + (m, l); backward: dQ) go through the caller's workspace and are folded by a small second kernel,
+ * in split order (deterministic).  Queries are DENSE [batch, sq <= 128] (q_sb / dq_sb strides); cu_k as above or NULL for dense keys.  Same
+ * results as the unsplit launch up to the order of fp32 additions (the softmax reference points are whole binades, so the bf16
+ * probabilities do not depend on where a walk over the keys starts).
+ *   _plan: ksplit for these extents (1 = do not split: more than 128 queries or fewer than 4,096 keys; never a function of the batch, so a
+ *   question's result does not depend on what it is batched with) and the workspace bytes of the two launches (16-byte aligned ws). */
 int emdr2_attention_splitkv_plan(int batch, int heads, int max_sq, int max_sk, int *ksplit, size_t *fwd_bytes, size_t *bwd_bytes);
 int emdr2_attention_fwd_splitkv(const void *q, int64_t q_sb, int64_t q_ss, int64_t q_sn, const void *k, int64_t k_sb, int64_t k_ss, int64_t k_sn,
                                 const void *v, int64_t v_sb, int64_t v_ss, int64_t v_sn, void *o, const int64_t *ids_q, const int64_t *ids_k,

@@ -137,7 +137,7 @@ def _kept_keys(mask_i):
 def _attention_probs_v_bf16(raw, mask, v, scale):
     """softmax(mask(raw * scale)) V the way the fused forward kernel rounds it (csrc/attention.hip).  The probabilities enter the P V product
     as bf16( exp2(s2 - m) ), s2 = score in log2 units, m = the kernel's LAZY running maximum: keys are consumed in steps of 32, and the
-    reference point m of a wave's 32 queries moves (to max(m, step maximum), per query) only in a step where some query of the wave exceeds
+    reference point m of a wave's 32 queries moves (to ceil(max(m, step maximum)), per query) only in a step where some query of the wave exceeds
     its m by more than 8 -- so which bf16 a probability rounds to depends on that sequence, and this function walks it.  The normaliser is
     the fp32 sum of the UNROUNDED exponentials, applied as a reciprocal to the fp32 product.  Keys that no query may see (padding) are not
     part of the sequence: the packed layout does not store them, and a trailing run of them changes nothing in the dense layout either.
@@ -162,7 +162,7 @@ def _attention_probs_v_bf16(raw, mask, v, scale):
             trig = bmax > m + 8.0                                        # per query; the kernel decides per wave of 32 queries
             tw = F.pad(trig, (0, nwave * 32 - sq)).reshape(heads, nwave, 32).any(dim=-1, keepdim=True).expand(-1, -1, 32)
             tw = tw.reshape(heads, nwave * 32)[:, :sq]
-            mnew = torch.where(tw, torch.maximum(m, bmax), m)
+            mnew = torch.where(tw, torch.ceil(torch.maximum(m, bmax)), m)     # (r05: a whole number of binades, csrc/attention.hip)
             alpha = torch.exp2(m - mnew)
             l, o, m = l * alpha, o * alpha[..., None], mnew
             pj = torch.exp2(sj - m[..., None])

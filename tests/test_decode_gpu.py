@@ -71,7 +71,11 @@ def test_incremental_decode_matches_the_oracle_decoder():
     compared = 0
     for q in range(B):
         for t in range(min(len(ref[q]), L)):
-            if float(margins[q, t]) < 0.05 * max(scale, 1e-3) + 2e-2:      # an arg-max bf16 cannot be asked to reproduce: sequences may part here
+            # an arg-max bf16 cannot be asked to reproduce: sequences may part here.  (Measured r05, teacher-forced along the oracle's path: the HIP
+            # logits of this 4x-weights toy reader sit 0.024 RMS / 0.24 max from the fp32 oracle's at a logit RMS of 0.57 -- the same with the
+            # fused attention's softmax reference point on whole binades (r05) as with the free-running one (0.023 / 0.29) -- so which near-ties
+            # flip is a draw; the band is 1.5 x that RMS above the 5 % of the median margin)
+            if float(margins[q, t]) < 0.05 * max(scale, 1e-3) + 3.6e-2:
                 break
             assert t < len(ours[q]) and ours[q][t] == ref[q][t], (q, t, ours[q], ref[q])
             compared += 1
@@ -139,7 +143,7 @@ def test_beam_search_matches_the_oracle_beam_search(with_eos):
         ours = _beam(m, qb, k, max_len)
         assert len(ours) == B
         for q in range(B):
-            if float(gaps[q]) > 1.2e-2:                                # log-probability units; the logits are O(0.5), bf16 round-off O(4e-3)
+            if float(gaps[q]) > 1.6e-2:                                # log-probability units; the logits are O(0.5), bf16 round-off O(4e-3) per op (0.024 RMS on the logits)
                 assert ours[q] == ref[q], (k, q, ours[q], ref[q], float(gaps[q]))
             early += ours[q] == ref[q] and len(ref[q]) < max_len
         assert sum(a == b for a, b in zip(ours, ref)) >= 10, (k, [(a, b, float(g)) for a, b, g in zip(ours, ref, gaps) if a != b])

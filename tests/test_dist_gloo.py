@@ -173,3 +173,90 @@ def test_index_builder_splits_batches_like_the_reference_sampler_and_merges_shar
     keys = list(store.embed_data)                                        # rank 0's rows first (its own shard), then rank 1's
     assert keys[:8] == list(range(1, 9)) and keys[8:16] == list(range(17, 25))
     assert not os.path.isdir(os.path.splitext(path)[0] + "_tmp")
+
+
+# ---- index (re)load on N ranks: only the first rank ever unpickles ---------------------------------------------
+def _load_worker(rank, world, port, path, log_path):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from emdr2_amd.data import emdr2_index as ei
+    real_read = ei.OpenRetreivalDataStore._read
+
+    def counting_read(p):
+        with open(log_path, "a") as fh:
+            fh.write("%d\n" % rank)
+        return real_read(p)
+    ei.OpenRetreivalDataStore._read = staticmethod(counting_read)
+
+    class Index(ei.DistributedBruteForceIndex):
+        def _make_shard(self, dim, n, base):
+            return _OracleShard(dim, n, base)
+
+    def expect(index, seed, n):
+        rng = np.random.default_rng(seed)
+        rows = rng.standard_normal((n, 64)).astype(np.float16)
+        ids = (rng.permutation(n) + 1).astype(np.int32)
+        lo, hi = ei.shard_bounds(n, world)[rank]
+        assert (index.shard.row_base, index.shard.n_rows) == (lo, hi - lo)
+        assert np.array_equal(np.asarray(index.shard._rows).view(np.uint16), rows[lo:hi].view(np.uint16)) and np.array_equal(index.shard.ids, ids[lo:hi])
+
+    # the retriever's form (emdr2_model.py: get_evidence_embedding): an UNLOADED store handed to the index
+    store = ei.OpenRetreivalDataStore(path, load_from_path=False, rank=rank)
+    index = Index(embed_size=64, embed_data=store, use_gpu=True)
+    expect(index, 1, 1001)
+    assert not store.embed_data                                           # no rank keeps a host copy of the dictionary
+    index.update_index()                                                  # nothing new on disk: the flat twin is reused, nobody unpickles
+    expect(index, 1, 1001)
+    dist.barrier()
+    if rank == 0:                                                         # "a new indexer job has rewritten --embedding-path"
+        rng = np.random.default_rng(2)
+        rows = rng.standard_normal((777, 64)).astype(np.float16)
+        ids = (rng.permutation(777) + 1).astype(np.int32)
+        fresh = ei.OpenRetreivalDataStore(path, load_from_path=False, rank=0)
+        fresh.add_block_data(ids.tolist(), rows)
+        fresh._write(path)
+        t = os.path.getmtime(ei.OpenRetreivalDataStore(path, load_from_path=False).flat_path()) + 5
+        os.utime(path, (t, t))
+    dist.barrier()
+    index.update_index()
+    expect(index, 2, 777)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_only_the_first_rank_unpickles_the_embedding_store(tmp_path):
+    """Start-up and `update_index()` on 3 ranks: rank 0 converts the reference's pickle to its flat twin once per new pickle, every rank maps
+    the flat file and loads only its own row range; ranks > 0 never unpickle (the reference: only the node-first rank does,
+    emdr2_model.py:414-423).  Row order = the pickle's dict order, torch.chunk shard bounds."""
+    from emdr2_amd.data.emdr2_index import FlatEmbeddingFile, OpenRetreivalDataStore
+    path, log_path = str(tmp_path / "emb.pkl"), str(tmp_path / "unpickles.log")
+    rng = np.random.default_rng(1)
+    rows = rng.standard_normal((1001, 64)).astype(np.float16)
+    ids = (rng.permutation(1001) + 1).astype(np.int32)
+    store = OpenRetreivalDataStore(path, load_from_path=False, rank=0)
+    store.add_block_data(ids.tolist(), rows)
+    store._write(path)
+    open(log_path, "w").close()
+    mp.spawn(_load_worker, args=(3, _free_port(), path, log_path), nprocs=3, join=True)
+    who = [int(x) for x in open(log_path).read().split()]
+    assert who == [0, 0], who                                             # once at start-up, once after the pickle was rewritten; never a rank > 0
+    flat = FlatEmbeddingFile(os.path.splitext(path)[0] + ".flat")
+    assert flat.n == 777 and flat.dim == 64
+
+
+def test_store_to_arrays_and_flat_file_are_block_gathers_of_the_dict(tmp_path):
+    """`to_arrays` / `FlatEmbeddingFile.from_store` gather the dictionary's values block by block (no per-row Python assignment) and keep its
+    insertion order, across block boundaries and for a ragged last block."""
+    from emdr2_amd.data.emdr2_index import FlatEmbeddingFile, OpenRetreivalDataStore
+    rng = np.random.default_rng(5)
+    rows = rng.standard_normal((2500, 8)).astype(np.float16)
+    ids = (rng.permutation(2500) + 1).astype(np.int32)
+    store = OpenRetreivalDataStore(str(tmp_path / "e.pkl"), load_from_path=False, rank=0)
+    store.add_block_data(ids.tolist(), rows)
+    blocks = list(store.iter_row_blocks(block_rows=1024))
+    assert [lo for lo, _ in blocks] == [0, 1024, 2048] and blocks[-1][1].shape == (452, 8)
+    i2, r2 = store.to_arrays()
+    assert np.array_equal(i2, ids) and np.array_equal(r2.view(np.uint16), rows.view(np.uint16))
+    flat = FlatEmbeddingFile.from_store(store, str(tmp_path / "e.flat"))
+    assert np.array_equal(flat.ids, ids) and np.array_equal(np.asarray(flat.rows).view(np.uint16), rows.view(np.uint16))

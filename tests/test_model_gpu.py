@@ -429,3 +429,37 @@ def test_dropout_mask_written_by_the_layernorm_backward_changes_nothing():
         assert torch.equal(o0, o1)
         for k in g0:
             assert _rel(g1[k], g0[k]) < 1e-6, (keep, sel, k, _rel(g1[k], g0[k]))
+
+
+@pytest.mark.parametrize("order", [0, 1])
+def test_premask_with_a_second_consumer_of_the_bias_dropout_add_output(order):
+    """y = x + dropout(z W^T + b) feeds a LayerNorm WITHOUT the residual hand-through AND a second autograd consumer, so
+    autograd sums two gradients for y -- possibly in place, into the very buffer the LayerNorm backward returned.  The masked copy that
+    backward left in kernels.PREMASK is mask(its own dx) only; the slot holds dx itself so the sum goes elsewhere and the stale copy is not
+    taken.  Gradients must equal the PREMASK-off run in both consumer orders."""
+    from emdr2_amd.model import kernels as K
+    H, T = 768, 512
+    g = torch.Generator(device="cuda").manual_seed(3)
+    mk = lambda *s: torch.randn(s, generator=g, device="cuda")
+    W = torch.nn.Parameter(mk(H, H) * 0.05); b = torch.nn.Parameter(mk(H) * 0.1)
+    gamma = torch.nn.Parameter(1 + 0.1 * mk(H)); beta = torch.nn.Parameter(0.1 * mk(H))
+    W2 = torch.nn.Parameter(mk(H, H) * 0.05)
+    z0, x0, w1, w2 = mk(T, H).bfloat16(), mk(T, H).bfloat16(), mk(T, H), mk(T, H)
+    res = {}
+    for enabled in (False, True):
+        for p in (W, b, gamma, beta, W2):
+            p.grad = None
+        z, x = z0.clone().requires_grad_(True), x0.clone().requires_grad_(True)
+        K.PREMASK.clear()
+        K.PREMASK.enabled, K.PREMASK.fused, K.PREMASK.unfused = enabled, 0, 0
+        try:
+            y = K.linear(z, W, b, residual=x, drop_p=0.1, seed=1234)
+            a = K.layer_norm(y, gamma, beta)                              # consumer 1: LayerNorm, no passthrough
+            c = K.linear(y, W2)                                           # consumer 2: another linear layer reading y
+            terms = [(a.float() * w1).sum(), (c.float() * w2).sum()]
+            (terms[order] + terms[1 - order]).backward()
+        finally:
+            K.PREMASK.enabled = True
+        res[enabled] = [t.grad.clone() for t in (z, x, W, b, gamma, beta, W2)]
+    for g0, g1 in zip(res[False], res[True]):
+        assert _rel(g1, g0) < 1e-6, _rel(g1, g0)
