@@ -307,21 +307,31 @@ def run(ctx, steps, warmup, world):
         allcs = [torch.empty_like(cs) for _ in range(world)]
         torch.distributed.all_gather(allcs, cs)
         replicas = [float(c.item()) for c in allcs]
-    # HBM traffic of the step's GEMM launches: per-kernel FETCH_SIZE x 2 / WRITE_SIZE (separate rocprofv3 --pmc passes over the kernels one by
-    # one, tools/r03_gemm_evidence.sh) weighted by the algorithmic bytes of every GEMM launch of a step -- committed summary, not measured live
-    traffic, traffic_note = None, "profiles/r03_gemm_summary.json not found"
-    prof = os.path.join(ROOT, "profiles", "r03_gemm_summary.json")
+    # HBM traffic of the step's GEMM launches: per-kernel FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes over the kernels one by one,
+    # tools/r05_evidence.sh), each access shape scaled by the factor measured on a known byte count on the same box
+    # (profiles/r05_fetch_calibration.json), weighted by the algorithmic bytes of every GEMM launch of a step -- a committed summary of THIS
+    # round's kernels, quoted only if it was taken from the very library that is loaded now
+    traffic, traffic_note = None, "profiles/r05_gemm_summary.json not found"
+    prof = os.path.join(ROOT, "profiles", "r05_gemm_summary.json")
     if os.path.exists(prof):
-        sw = json.load(open(prof)).get("step_weighted_traffic")
-        if sw:
+        import hashlib
+        pj = json.load(open(prof))
+        sw = pj.get("step_weighted_traffic")
+        with open(_native.LIB_PATH, "rb") as fh:
+            loaded = hashlib.sha256(fh.read()).hexdigest()
+        if pj.get("library_sha256") != loaded:
+            traffic_note = ("profiles/r05_gemm_summary.json was measured on another build of libemdr2_hip.so (sha256 %s..., loaded %s...): not quoted"
+                            % (str(pj.get("library_sha256"))[:12], loaded[:12]))
+        elif sw:
+            cal = pj.get("calibration", {})
             traffic = {"hbm_read_gb_per_step": sw["measured_read_gb"], "algorithmic_read_gb_per_step": sw["algorithmic_read_gb"], "read_ratio": sw["read_ratio"],
-                       "hbm_write_gb_per_step_uncalibrated": sw["measured_write_gb_uncalibrated"], "algorithmic_write_gb_per_step": sw["algorithmic_write_gb"],
-                       "write_ratio_uncalibrated": sw["write_ratio_uncalibrated"]}
-            traffic_note = ("step-weighted over the GEMM launches of one step (%.0f of %.0f ms covered) from profiles/r03_gemm_summary.json: per (kind, N, K, "
-                            "epilogue) FETCH_SIZE x 2 (the gfx950 correction for 16-byte LDS-DMA streams; the epilogues' residual / pre-activation rows are read "
-                            "with another access shape for which the x 2 is uncalibrated, so their ratios -- and this aggregate -- are upper bounds) and "
-                            "WRITE_SIZE; operand-only kernels: 1.16 (N = K = 768), 1.34 (K = 3072), 2.4 - 3.8 (N = 2304 / 3072: B panels re-fetched once "
-                            "per round and XCD, DESIGN.md 11)" % (sw["covered_ms"], sw["all_ms"]))
+                       "hbm_write_gb_per_step": sw["measured_write_gb_uncalibrated"], "algorithmic_write_gb_per_step": sw["algorithmic_write_gb"],
+                       "write_ratio": sw["write_ratio_uncalibrated"], "calibration": cal}
+            traffic_note = ("step-weighted over the GEMM launches of one step (%.0f of %.0f ms covered) from profiles/r05_gemm_summary.json (same library: sha256 "
+                            "%s...): per (kind, N, K, epilogue) FETCH_SIZE / WRITE_SIZE, the LDS-DMA operand stream, the epilogue's residual-row reads and "
+                            "its row-segment stores each scaled by the factor measured for THAT access shape on a known byte count "
+                            "(profiles/r05_fetch_calibration.json; calibrated_on_this_box = %s)" % (sw["covered_ms"], sw["all_ms"], loaded[:12],
+                                                                                               cal.get("calibrated_on_this_box")))
     ctx.keep_last, ctx.selective = ctx.plan["keep"], (ctx.plan["reader"], ctx.plan["context"])       # (thinned if a step ran out of memory)
     fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)
     sps = steps / elapsed
@@ -340,6 +350,9 @@ def run(ctx, steps, warmup, world):
                    "tokens_padded": (Kmod.PACKING.grid_tokens // steps) if Kmod.PACKING.enabled else
                                     ctx.B * ctx.S_ret + ctx.B * ctx.K * ctx.S_ret + 2 * ctx.B * ctx.K * ctx.S,
                    "question_micro_batches": ctx.guard.micro,
+                   # north_star quotes two tolerances (1e-3 fp32 / 2e-2 bf16): this build computes in bf16 only; there is no fp32 compute mode
+                   # (waiver).  Everything measured and tested here is held to the bf16 bar against a bf16-faithful oracle.
+                   "fp32_mode": "not built",
                    "dropout": ctx.dropout, "activation_recompute": ("none: forward + backward in %d groups of %d questions, every activation of a group kept" % (ctx.guard.micro, ctx.B // ctx.guard.micro)) if ctx.guard.micro > 1 else "per layer" + (", except the last %d reader-encoder layers (all activations kept in HBM)" % ctx.keep_last if ctx.keep_last else "") +
                                            ("; selective retention (6 of ~16 [tokens, h] tensors kept, LayerNorm outputs + FFN intermediates rebuilt in the backward) "
                                             "on %d reader-encoder and %d context-tower layers" % ctx.selective if sum(ctx.selective) else ""),

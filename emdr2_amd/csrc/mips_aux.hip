@@ -274,7 +274,12 @@ __device__ __forceinline__ void select_block(SelectShared &sh, uint2 *cand_all, 
         prefix |= (uint64_t)sh.digit << shift;
         mask |= (uint64_t)0xff << shift;
         need = sh.need;
+        const unsigned same = sh.hist[sh.digit];                      // keys that share the prefix so far
         __syncthreads();
+        // r05: the upper half of a key is its fp32 score, the lower half only breaks ties by row.  Once the four score digits are fixed and ALL
+        // keys with that score are wanted (no tie across the boundary: the usual case), every key >= (score, row bits 0) is in and the four
+        // row passes have nothing to decide: half of every select's passes.
+        if (pass == 3 && same == need) break;
     }
     // prefix is now the kp-th largest key; keys are unique, so exactly kp keys are >= prefix
     if (tid == 0) sh.out = 0;
@@ -329,6 +334,42 @@ __device__ __forceinline__ void exact_dot_wave(const char *e_tiled, int64_t row,
     hi_out = wave_sum_i64(hi);
 }
 
+// Four candidates of one wave at a time (dim <= 1024: a row is <= 2 segments per lane): all eight row loads go out before the first is
+// used.  One candidate after the other, each of a wave's 16 - 32 candidates paid a full memory latency for its scattered 16-byte row segments
+// (r04: ~50 of the finalize launch's 82 us on an N / 8 shard); the integer arithmetic itself is a few hundred instructions per candidate.
+__device__ __forceinline__ void exact_dot_wave_x4(const char *e_tiled, const unsigned (&rows)[4], int n_valid, const uint16_t *qrow, int nseg, int lane,
+                                                  int64_t (&lo_out)[4], int64_t (&hi_out)[4])
+{
+    const bool two = lane + 64 < nseg, one = lane < nseg;
+    uint4 ev[4][2];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        ev[c][0] = ev[c][1] = make_uint4(0, 0, 0, 0);
+        if (c < n_valid) {
+            if (one) ev[c][0] = *(const uint4 *)(e_tiled + tiled_seg_offset((int64_t)rows[c], lane, nseg >> 2));
+            if (two) ev[c][1] = *(const uint4 *)(e_tiled + tiled_seg_offset((int64_t)rows[c], lane + 64, nseg >> 2));
+        }
+    }
+    uint4 qv[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+    if (one) qv[0] = *(const uint4 *)(qrow + lane * 8);
+    if (two) qv[1] = *(const uint4 *)(qrow + (lane + 64) * 8);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        int64_t lo = 0, hi = 0;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const uint32_t ew[4] = {ev[c][h].x, ev[c][h].y, ev[c][h].z, ev[c][h].w}, qw[4] = {qv[h].x, qv[h].y, qv[h].z, qv[h].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {                          // (absent segments hold zeros: mantissa 0, nothing added)
+                exact_mac(lo, hi, half_fix((uint16_t)(ew[j] & 0xffff)), half_fix((uint16_t)(qw[j] & 0xffff)));
+                exact_mac(lo, hi, half_fix((uint16_t)(ew[j] >> 16)), half_fix((uint16_t)(qw[j] >> 16)));
+            }
+        }
+        lo_out[c] = wave_sum_i64(lo);
+        hi_out[c] = wave_sum_i64(hi);
+    }
+}
+
 template <bool SELECT_FIRST>
 __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
 {
@@ -349,12 +390,31 @@ __global__ void __launch_bounds__(256) finalize_kernel(FinalizeParams p)
     const int nseg = p.dim / 8;
     const uint16_t *qrow = p.queries + (size_t)q * p.dim;
 
-    for (unsigned j = wave; j < cnt; j += 4) {
-        const unsigned row = cand[j].y;
-        int64_t lo, hi;
-        exact_dot_wave(p.e_tiled, (int64_t)row, qrow, nseg, lane, lo, hi);
-        const uint32_t ord = p.f32 ? f32_order(fixed_to_float(lo, hi)) : h16_order(fixed_to_half(lo, hi));
-        if (lane == 0) fkey[j] = ((uint64_t)ord << 32) | (uint64_t)(0xffffffffu - row);
+    if (nseg <= 128) {
+        for (unsigned j0 = wave; j0 < cnt; j0 += 16) {                        // this wave's candidates j0, j0 + 4, j0 + 8, j0 + 12 together
+            unsigned rows[4];
+            int nv = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { const unsigned j = j0 + 4 * c; rows[c] = j < cnt ? cand[j].y : 0u; nv += j < cnt; }
+            int64_t lo[4], hi[4];
+            exact_dot_wave_x4(p.e_tiled, rows, nv, qrow, nseg, lane, lo, hi);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const unsigned j = j0 + 4 * c;
+                if (j < cnt && lane == 0) {
+                    const uint32_t ord = p.f32 ? f32_order(fixed_to_float(lo[c], hi[c])) : h16_order(fixed_to_half(lo[c], hi[c]));
+                    fkey[j] = ((uint64_t)ord << 32) | (uint64_t)(0xffffffffu - rows[c]);
+                }
+            }
+        }
+    } else {
+        for (unsigned j = wave; j < cnt; j += 4) {
+            const unsigned row = cand[j].y;
+            int64_t lo, hi;
+            exact_dot_wave(p.e_tiled, (int64_t)row, qrow, nseg, lane, lo, hi);
+            const uint32_t ord = p.f32 ? f32_order(fixed_to_float(lo, hi)) : h16_order(fixed_to_half(lo, hi));
+            if (lane == 0) fkey[j] = ((uint64_t)ord << 32) | (uint64_t)(0xffffffffu - row);
+        }
     }
     if (tid == 0) sh_kth = 0;
     __syncthreads();

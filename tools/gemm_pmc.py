@@ -13,13 +13,16 @@ Collect with one pass per counter group (never together with the hip/hsa trace d
 import collections
 import csv
 import glob
+import hashlib
 import json
 import os
 import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-M_FULL = 3200 * 512
+# token rows per launch: r02-r04 profiled the undivided batch (3,200 x 512); since r05 the step runs its questions in groups
+# (EMDR2Model.forward_backward) and a reader-encoder group of 16 questions x 50 passages packs to 327,680 rows
+M_FULL = int(os.environ.get("EMDR2_GEMM_PMC_M", 327680))
 LAUNCHES = 3
 # (kind, M, N, K, epilogue)
 CONFIGS = [("nt", M_FULL, N, K, e) for N, K in ((768, 768), (2304, 768), (3072, 768), (768, 3072))
@@ -59,7 +62,19 @@ def run():
         torch.cuda.synchronize()
 
 
-def summarize(dirs, shapes_json, out):
+def library_sha256():
+    from emdr2_amd import _native
+    with open(_native.LIB_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()
+
+
+def summarize(dirs, shapes_json, out, calibration_json=""):
+    cal = {"read_stream": 2.0, "read_rowseg": 2.0, "read_lds_dma": 2.0, "write_stream": 1.0, "write_rowseg": 1.0}
+    calibrated = False
+    if calibration_json and os.path.exists(calibration_json):
+        f_ = json.load(open(calibration_json)).get("factors", {})
+        cal.update({k: v for k, v in f_.items() if v})
+        calibrated = all(f_.get(k) for k in ("read_rowseg", "read_lds_dma", "write_rowseg"))
     per = [dict(kind=k, M=M, N=N, K=Kd, epilogue=e, counters={}) for k, M, N, Kd, e in CONFIGS]
     for d in dirs:
         cc = glob.glob(os.path.join(d, "*", "*counter_collection.csv"))
@@ -100,10 +115,18 @@ def summarize(dirs, shapes_json, out):
         cfg["algorithmic_read_gb"], cfg["algorithmic_write_gb"] = round(rd / 1e9, 3), round(wr / 1e9, 3)
         cfg["algorithmic_hbm_gb"] = round((rd + wr) / 1e9, 3)
         if "FETCH_SIZE" in c:
-            cfg["hbm_read_gb"] = round(2.0 * c["FETCH_SIZE"] * 1024 / 1e9, 3)          # KB, x2: gfx950 tallies 128-B read requests at 64 B
+            # FETCH_SIZE (KiB) counts each access shape at its own rate (profiles/r05_fetch_calibration.json): the epilogue's residual /
+            # saved-gelu' rows are read exactly once (every element by one lane) -- their share of the counter is their bytes / read_rowseg --
+            # and what is left is the LDS-DMA operand stream, scaled by read_lds_dma.  TN: both operands are LDS-DMA streams.
+            resid = (rd - 2.0 * (cfg["M"] * cfg["K"] + cfg["N"] * cfg["K"])) if cfg["kind"] == "nt" else 0.0
+            counted = c["FETCH_SIZE"] * 1024.0
+            operands = max(0.0, counted - resid / cal["read_rowseg"]) * cal["read_lds_dma"]
+            cfg["hbm_read_gb"] = round((operands + resid) / 1e9, 3)
             cfg["read_ratio"] = round(cfg["hbm_read_gb"] / cfg["algorithmic_read_gb"], 3)
+            cfg["operand_read_ratio"] = round(operands / (rd - resid), 3)
         if "WRITE_SIZE" in c:
-            cfg["hbm_write_gb_uncalibrated"] = round(c["WRITE_SIZE"] * 1024 / 1e9, 3)
+            wf = cal["write_rowseg"] if cfg["kind"] == "nt" else cal["write_stream"]
+            cfg["hbm_write_gb_uncalibrated"] = round(c["WRITE_SIZE"] * 1024 * wf / 1e9, 3)          # (key kept; calibrated when `calibrated` below says so)
             cfg["write_ratio_uncalibrated"] = round(cfg["hbm_write_gb_uncalibrated"] / cfg["algorithmic_write_gb"], 3)
         if "SQ_VALU_MFMA_BUSY_CYCLES" in c and "GRBM_GUI_ACTIVE" in c:
             # MFMA-busy cycles are summed over the 1,024 SIMDs, GRBM_GUI_ACTIVE over the 8 XCDs
@@ -112,8 +135,9 @@ def summarize(dirs, shapes_json, out):
         if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
             cfg["l2_hit_rate"] = round(c["TCC_HIT_sum"] / (c["TCC_HIT_sum"] + c["TCC_MISS_sum"]), 3)
         cfg["counters"] = {k: round(v, 1) for k, v in sorted(c.items())}
-    res = {"what": "reader GEMM kernels one by one at the end-to-end step's shapes (M = 3200 x 512 token rows): %d launches per configuration, mean per launch; "
-                   "counters from separate rocprofv3 --pmc passes (kernel-trace only)" % LAUNCHES,
+    res = {"what": "reader GEMM kernels one by one at the end-to-end step's shapes (M = %d token rows): %d launches per configuration, mean per launch; "
+                   "counters from separate rocprofv3 --pmc passes (kernel-trace only)" % (M_FULL, LAUNCHES),
+           "library_sha256": library_sha256(), "calibration": dict(cal, calibrated_on_this_box=calibrated, source=os.path.basename(calibration_json or "")),
            "notes": ["tflops_under_pmc is measured while counters are being collected (a few % slower than free-running)",
                      "hbm_read_gb = 2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md, HBM section); WRITE_SIZE is reported as is",
                      "mfma_busy_frac = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8 XCDs): the fraction of cycles the matrix pipe works, at the "
@@ -159,8 +183,9 @@ if __name__ == "__main__":
     elif len(sys.argv) > 1 and sys.argv[1] == "summarize":
         args = sys.argv[2:]
         shapes = args[args.index("--shapes") + 1] if "--shapes" in args else ""
+        calib = args[args.index("--calibration") + 1] if "--calibration" in args else ""
         out = args[args.index("--out") + 1]
-        dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] not in ("--shapes", "--out"))]
-        summarize(dirs, shapes, out)
+        dirs = [a for i, a in enumerate(args) if not a.startswith("--") and (i == 0 or args[i - 1] not in ("--shapes", "--out", "--calibration"))]
+        summarize(dirs, shapes, out, calib)
     else:
         print(__doc__)

@@ -45,5 +45,9 @@ if w:
 if f and w:
     res["traffic_bytes"] = res["hbm_read_bytes_corrected_x2"] + res["hbm_write_bytes"]
     res["traffic_over_algorithmic"] = res["traffic_bytes"] / res["algorithmic_bytes_last_segment"]
+import hashlib
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from emdr2_amd import _native  # noqa: E402
+res["library_sha256"] = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()     # bench.py quotes the summary only for this very build
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))
