@@ -15,6 +15,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--questions", default="64,16,8")
 ap.add_argument("--topk", type=int, default=50)
 ap.add_argument("--drop", type=float, default=0.1)
+ap.add_argument("--only-fid-cross", action="store_true", help="time only the FiD cross-attention (for per-kernel traces)")
 args = ap.parse_args()
 heads, hn, L = 12, 64, 32
 g = torch.Generator(device="cuda").manual_seed(0)
@@ -56,8 +57,9 @@ for b in (int(v) for v in args.questions.split(",")):
         ids = (torch.arange(S, device="cuda")[None, :] < lens[:, None]).long() * 7
         seqs = K.PackedSeqs(ids)
         qkv = torch.randn((seqs.rows, 3, heads, hn), generator=g, device="cuda").bfloat16().requires_grad_(True)
-        case("%s (self, %d rows)" % (name, seqs.rows), qkv, None, seqs, seqs, seqs.pairs)
-        if name != "context tower":
+        if not args.only_fid_cross:
+            case("%s (self, %d rows)" % (name, seqs.rows), qkv, None, seqs, seqs, seqs.pairs)
+        if name != "context tower" and (name == "reader encoder" or not args.only_fid_cross):
             # the decoder's cross-attention over these encoder rows: FiD = b questions x L positions over the K passages of a question;
             # one-context = b*K sequences x L positions over one passage each
             grp = seqs.grouped(args.topk) if name == "reader encoder" else seqs

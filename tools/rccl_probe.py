@@ -26,9 +26,20 @@ out = torch.empty(world * y.numel(), dtype=torch.int64, device=dev)
 torch.cuda.synchronize(); t0 = time.perf_counter()
 dist.all_gather_into_tensor(out, y); torch.cuda.synchronize()
 t_ag = time.perf_counter() - t0
+# r05: the sharded search's exchange -- every rank's 16-byte records written into ITS slice of the gather buffer, gathered IN PLACE (the slice
+# is the send buffer: ncclAllGather's in-place form, sendbuff == recvbuff + rank * count), then merged by the HIP kernel
+nq, k = 512, 50
+gathered = torch.zeros((world, nq, k, 16), dtype=torch.uint8, device=dev)
+gathered[rank] = (torch.arange(nq * k * 16, device=dev) % 251 + rank).to(torch.uint8).view(nq, k, 16)
+expect = torch.stack([(torch.arange(nq * k * 16, device=dev) % 251 + r).to(torch.uint8).view(nq, k, 16) for r in range(world)])
+torch.cuda.synchronize(); t0 = time.perf_counter()
+dist.all_gather_into_tensor(gathered.view(-1, k, 16), gathered[rank]); torch.cuda.synchronize()
+t_inplace = time.perf_counter() - t0
+inplace_ok = bool(torch.equal(gathered, expect))
 dist.barrier(); torch.cuda.synchronize()
 if rank == 0:
     print(json.dumps({"backend": dist_util.backend_name(), "world": world, "rccl_version": list(torch.cuda.nccl.version()),
                       "allreduce_512MB_bf16_ms": t_ar * 1e3, "allreduce_ok": bool(float(x[0]) == world), "allgather_topk_block_ms": t_ag * 1e3,
-                      "allgather_ok": bool(int(out[-1]) == y.numel() - 1 + world - 1)}))
+                      "allgather_ok": bool(int(out[-1]) == y.numel() - 1 + world - 1),
+                      "allgather_records_in_place_ms": t_inplace * 1e3, "allgather_records_in_place_ok": inplace_ok}))
 dist_util.shutdown()
