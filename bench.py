@@ -53,7 +53,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="MIPS half only")
-    ap.add_argument("--e2e-steps", type=int, default=3)
+    ap.add_argument("--e2e-steps", type=int, default=5)
     ap.add_argument("--e2e-warmup", type=int, default=1)
     ap.add_argument("--e2e-timeout", type=float, default=480.0, help="seconds after which rank 0 prints the line without the unfinished e2e objects and exits")
     ap.add_argument("--no-e2e-k100", action="store_true",

@@ -214,3 +214,35 @@ def test_plain_bench_e2e_command_with_two_gpus():
     assert r["metric"] == "qa_train_steps_per_sec" and r["n_gpus"] == 2 and r["value"] > 0 and r["scaling"] == "weak"
     cs = r["config"]["replica_parameter_checksums"]
     assert len(cs) == 2 and cs[0] == cs[1], cs
+
+
+def test_config3_surrogate_two_ranks_full_depth_full_index():
+    """BASELINE configs[3] as far as a 1-GPU box goes ("configs[3] only as world-size-2 surrogates at B = 4 / 2 layers"): the PLAIN
+    `bench_e2e.py --gpus 2` command at the benchmark's depth and index -- all 12 layers of the four stacks (440 M parameters), the whole
+    21,015,324-row index row-sharded over the two ranks (10.5 M rows each), top-k 50, S_ret 256 / S 512 / L 32, bf16, question groups with
+    nothing recomputed -- at B = 16 questions per rank (two processes share the one GPU's 288 GB; 8 ranks x B = 64 need 8 GPUs).  Every
+    collective of the step runs: all-gather of the queries, the record all-gather + merge of the sharded search, the bucketed bf16 gradient
+    all-reduce overlapped with the last group's backward; the two replicas must end with bit-identical parameters."""
+    import json
+    import subprocess
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = [sys.executable, "bench_e2e.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "21015324", "--batch", "16", "--layers", "12"]
+    out = subprocess.run(cmd, env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=1200)
+    assert out.returncode == 0, out.stderr.decode()[-3000:]
+    lines = [l for l in out.stdout.decode().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    r = json.loads(lines[0])
+    c = r["config"]
+    assert r["n_gpus"] == 2 and r["value"] > 0 and c["global_batch"] == 32 and c["params"] == 440388096
+    assert "21015324-row index" in c["workload"] and "12 layers" in c["workload"] and c["parallelism"] == "dp2 (index row-sharded x2)"
+    assert c["question_micro_batches"] == 4 and c["recompute_tflop_per_step"] == 0 and c["steps_rerun_after_out_of_memory"] == 0
+    cs = c["replica_parameter_checksums"]
+    assert len(cs) == 2 and cs[0] == cs[1], cs
+    assert np_isfinite(c["loss"])
+
+
+def np_isfinite(x):
+    import math
+    return math.isfinite(float(x))
