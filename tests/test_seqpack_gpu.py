@@ -206,7 +206,9 @@ def test_cross_attention_over_packed_keys_equals_dense(B, Kk, S, L, heads):
     # packed / dense layouts cut their key ranges at different places: the fp32 partial sums meet in another order, a bf16 output may move by
     # one step (largest shape); smaller shapes do not split and agree to fp32 round-off
     assert _rel(out_p[dreal], out_d[dreal]) < (8e-3 if Kk * S > 4096 else 1e-5)
-    assert float((out_p[dreal].float() - out_d[dreal].float()).abs().mean() / out_d[dreal].float().abs().mean()) < 1e-3
+    # (measured r05 on the largest shape: 0.6 % of the outputs move by one bf16 step, mean relative difference 2e-5 -- 2e-3 before the softmax
+    # reference points were put on whole binades, when every probability rounded differently in the two layouts)
+    assert float((out_p[dreal].float() - out_d[dreal].float()).abs().mean() / out_d[dreal].float().abs().mean()) < 2e-4
     (out_p.float() * w).sum().backward()
     assert _rel(q.grad[dreal], gq[dreal]) < 2e-3
     assert _rel(kv.grad[real], gkv[real]) < 2e-3 and float(kv.grad[~real].abs().max()) == 0.0
@@ -253,7 +255,7 @@ def test_split_key_launches_equal_the_unsplit_launch(drop_p):
         o2, dq2, dkv2 = run(kv, ids_k, False)
         # (bf16 outputs: a different order of the fp32 additions may move a value by one bf16 step)
         assert _rel(o2, o1) < 8e-3 and bool(torch.isfinite(o2.float()).all()), _rel(o2, o1)
-        assert float((o2.float() - o1.float()).abs().mean() / o1.float().abs().mean()) < 1e-3
+        assert float((o2.float() - o1.float()).abs().mean() / o1.float().abs().mean()) < 2e-4
         assert _rel(dq2, dq1) < 1e-2, _rel(dq2, dq1)
         assert _rel(dkv2, dkv1) < 1e-2, _rel(dkv2, dkv1)                 # (dk / dv see the statistics the split forward left)
         o3, dq3, dkv3 = run(kv, ids_k, False)                            # partials are folded in split order: bit-reproducible
