@@ -193,3 +193,31 @@ def test_weight_decay_groups_of_our_model_are_the_reference_groups():
         for p in b["params"]:
             o = opt.slot[p][1]
             assert (o < b["split"]) == (names[id(p)] in ref["weight_decay"]) or not p.requires_grad
+
+
+def test_task_entry_point_on_two_ranks_with_question_groups_and_the_refresher(tmp_path):
+    """The task driver as the shipped scripts launch it, on TWO ranks (gloo transport, both on the test GPU): `--embedding-path` is unpickled by
+    rank 0 only and loaded through its flat twin, the index is row-sharded, every search is all-gather(queries) + record all-gather + merge,
+    the step runs in question groups (`--question-micro-batches 2`: forward + backward per group, bucketed bf16 gradient exchange on the last
+    group's backward), the side-stream refreshers of the two ranks agree on the swap (MIN all-reduce in `maybe_swap`), checkpoints and the
+    EM evaluation run on both ranks."""
+    import subprocess
+    import sys
+    from emdr2_amd import checkpointing
+    tmp = str(tmp_path)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, EMDR2_SINGLE_DEVICE="1", EMDR2_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(root, "tools", "dryrun_task.py"), tmp, "--question-micro-batches", "2"]
+    out = subprocess.run(cmd, env=env, cwd=root, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    assert "rank 0 done" in text and "rank 1 done" in text
+    assert "MIPS Index Updated" in text and "lm_loss" in text and "Exact Match Score" in text
+    assert os.path.exists(os.path.join(tmp, "emb.flat"))                 # written once by rank 0, mapped by both
+    it, release = checkpointing.read_tracker(os.path.join(tmp, "ckpt"))
+    assert it == 3 and not release                                        # 24 questions / (batch 4 x 2 ranks), one epoch

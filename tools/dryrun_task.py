@@ -15,5 +15,5 @@ while not os.path.exists(os.path.join(tmp, "READY")):
     time.sleep(0.2)
 vocab, ev, emb = open(os.path.join(tmp, "READY")).read().split("\n")
 from emdr2_amd.tasks import run as task_run
-model, results = task_run.main(T._argv(tmp, vocab, ev, emb))
+model, results = task_run.main(T._argv(tmp, vocab, ev, emb, extra=sys.argv[2:]))          # (further task flags after the directory)
 print("rank %d done: validation %s" % (rank, results.get("validation")), flush=True)
