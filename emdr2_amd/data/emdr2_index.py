@@ -533,9 +533,6 @@ class DistributedBruteForceIndex(object):
     def _make_shard(self, dim, n_rows, row_base):
         return HipIndexShard(dim, n_rows, row_base)
 
-    def _merge(self, dist, idx, row):
-        return merge_shard_results(dist, idx, row)
-
     # -- reference API -------------------------------------------------------------------------------
     def _set_mips_index(self):
         if self.embed_data is not None:
@@ -686,6 +683,3 @@ class FaissMIPSIndex(DistributedBruteForceIndex):
         local = (row - self.shard.row_base).clamp(min=0).reshape(-1)
         vecs = self.shard.rows(local).to(torch.float32).reshape(row.shape[0], row.shape[1], self.embed_size)
         return distances, indices, vecs.cpu().numpy()
-
-    def _merge_f32(self, dist, idx, row):
-        return merge_shard_results_f32(dist, idx, row)
