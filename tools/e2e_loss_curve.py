@@ -25,8 +25,9 @@ for i in range(args.steps):
     losses.append(float(loss.detach()))
 torch.cuda.synchronize()
 from emdr2_amd.model import kernels as Kmod
-res = {"workload": "bench_e2e.py step, B=%d, top-k %d, %d layers, %d-row index, lr warm-up 10 steps to 2e-5, dropout %.1f, packed sequences %s, selective retention %s"
-                   % (ctx.B, ctx.K, ctx.layers, ctx.rows, ctx.dropout, Kmod.PACKING.enabled, args.selective_layers),
+res = {"workload": "bench_e2e.py step, B=%d, top-k %d, %d layers, %d-row index, lr warm-up 10 steps to 2e-5, dropout %.1f, packed sequences %s, question "
+                   "micro-batches %d (1 = undivided, selective retention %s)"
+                   % (ctx.B, ctx.K, ctx.layers, ctx.rows, ctx.dropout, Kmod.PACKING.enabled, ctx.guard.micro, args.selective_layers),
        "loss_per_step": losses, "seconds": time.perf_counter() - t0}
 print(json.dumps(res))
 if args.out:
