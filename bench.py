@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--no-e2e-k100", action="store_true",
                     help="skip the `e2e_k100` object: BASELINE configs[4] (top-k 100 + continuous re-embedding on a side stream) at its per-rank "
                          "shape -- the N/8-row index shard of an 8-GPU run -- timed with and without the refresher")
-    ap.add_argument("--k100-steps", type=int, default=2)
+    ap.add_argument("--k100-steps", type=int, default=3)
     ap.add_argument("--no-clustered", action="store_true", help="skip the `clustered` object: the same search over a topic-contiguous, anisotropic corpus")
     import bench_e2e
     bench_e2e.add_args(ap)
