@@ -94,3 +94,21 @@ def test_ops_entry_points_validate_arguments_without_a_gpu(lib):
     assert lib.emdr2_attention_fwd(*args_f, 128, 64, 0, 0.125, 1.5, 0, None, None, None) == -1
     assert lib.emdr2_dropout(one, one, 64, 12, 0.1, 1, None) == -1          # cols % 8
     assert lib.emdr2_layernorm_fwd(one, one, one, one, one, one, 4, 12, 1e-5, None) == -1
+
+
+def test_r05_entry_points_validate_their_arguments(lib):
+    """The packed-record exchange and the split-key attention entries (ABI 3): bad pointers are refused without touching a GPU, and the
+    split-key plan -- a pure function of the query / key extents, never of the batch -- says what include/emdr2_ops.h says."""
+    assert lib.emdr2_mips_search_records(None, 10, 64, 0, None, None, 1, 1, None, 0, None, None, None, 0, None) == -1
+    assert lib.emdr2_mips_merge_records(None, 2, 4, 5, 0, None, None, None, None) == -1
+    assert lib.emdr2_mips_pack_records(None, None, None, None, 0, 5, 0, None, None) == -1
+    ks, fb, bb = ctypes.c_int(), ctypes.c_size_t(), ctypes.c_size_t()
+
+    def plan(batch, heads, sq, sk):
+        assert lib.emdr2_attention_splitkv_plan(batch, heads, sq, sk, ctypes.byref(ks), ctypes.byref(fb), ctypes.byref(bb)) == 0
+        return ks.value, fb.value, bb.value
+    assert plan(16, 12, 32, 25600) == (13, 13 * 16 * 12 * 32 * 66 * 4, 13 * 16 * 12 * 32 * 64 * 4)       # 400 key blocks in ranges of 32
+    assert plan(64, 12, 32, 25600)[0] == plan(1, 12, 32, 25600)[0] == 13                               # the batch does not enter
+    assert plan(16, 12, 32, 4095) == (1, 0, 0) and plan(16, 12, 32, 4096)[0] == 2                       # short key sets never split
+    assert plan(16, 12, 129, 25600) == (1, 0, 0) and plan(16, 12, 128, 65536)[0] == 32                 # one query block only
+    assert lib.emdr2_attention_splitkv_plan(0, 12, 32, 25600, ctypes.byref(ks), ctypes.byref(fb), ctypes.byref(bb)) == -1
