@@ -10,9 +10,13 @@ bench_e2e.add_args(ap)
 ap.add_argument("--rows", type=int, default=2_626_916)
 ap.add_argument("--topk", type=int, default=50)
 ap.add_argument("--max-decode-len", type=int, default=32)
+ap.add_argument("--no-split-keys", action="store_true", help="A/B: the cross-attention of the decoding steps as ONE workgroup per (question, head) (r04)")
 args = ap.parse_args()
 torch.cuda.set_device(0)
 ctx = bench_e2e.setup(args, 0, 1, topk=args.topk)
+if args.no_split_keys:
+    from emdr2_amd.model import kernels as _K
+    _K._splitkv_plan = lambda *a: (1, 0, 0)
 from emdr2_amd.model.search_strategy import SampleOrGreedySearch
 m = ctx.model.eval()
 B = args.batch
