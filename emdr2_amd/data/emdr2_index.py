@@ -217,10 +217,17 @@ def ensure_flat_embedding_file(embedding_path, process_group=None, log=None):
     err = None
     if rank == 0:
         try:
-            stale = (not os.path.exists(flat)) or os.path.getmtime(flat) < os.path.getmtime(embedding_path)
+            # the twin remembers WHICH pickle it was made from (size + modification time in ns, in a sidecar): a pickle rewritten by a new
+            # indexer job -- even within the same second -- makes it stale; an unchanged one is never converted twice
+            st = os.stat(embedding_path)
+            stamp = "%d %d" % (st.st_size, st.st_mtime_ns)
+            side = flat + '.src'
+            stale = not (os.path.exists(flat) and os.path.exists(side) and open(side).read().strip() == stamp)
             if stale:
                 store = OpenRetreivalDataStore(embedding_path, load_from_path=True, rank=0)
                 FlatEmbeddingFile.from_store(store, flat)
+                with open(side, 'w') as fh:
+                    fh.write(stamp)
                 if log:
                     log("converted %s (%d embeddings) to %s" % (embedding_path, len(store.embed_data), flat))
                 store.clear()
@@ -536,7 +543,10 @@ class DistributedBruteForceIndex(object):
     # -- reference API -------------------------------------------------------------------------------
     def _set_mips_index(self):
         if self.embed_data is not None:
-            if not self.embed_data.embed_data and getattr(self.embed_data, "embedding_path", None) and os.path.exists(self.embed_data.embedding_path):
+            path = getattr(self.embed_data, "embedding_path", None)
+            if not self.embed_data.embed_data and path and not os.path.exists(path) and getattr(self.embed_data, "_lazy", False):
+                raise FileNotFoundError("evidence embeddings not found: %s" % path)     # (what an eager load would have said)
+            if not self.embed_data.embed_data and path and os.path.exists(path):
                 # a store that has not been loaded (load_from_path=False): go through the flat twin of its file -- rank 0 converts, every
                 # rank maps its own rows; no rank but the first ever unpickles
                 self.add_flat_file(ensure_flat_embedding_file(self.embed_data.embedding_path, self.process_group))
@@ -549,6 +559,7 @@ class DistributedBruteForceIndex(object):
             embed_data_path = self.embed_data.embedding_path
             del self.embed_data
             self.embed_data = OpenRetreivalDataStore(embed_data_path, load_from_path=False)      # (loaded through its flat twin below)
+            self.embed_data._lazy = True
         self._set_mips_index()
 
     def update_index(self):

@@ -43,6 +43,7 @@ class PreComputedEvidenceDocsRetriever(object):
         # once, every rank maps its own rows; emdr2_index.ensure_flat_embedding_file) -- the reference unpickles on the node-first rank
         # only (emdr2_model.py:414-423), which one process per GPU would turn into 8 x 70 GB of host memory
         self.evidence_embedder_obj = OpenRetreivalDataStore(path, load_from_path=False)
+        self.evidence_embedder_obj._lazy = True                # a missing file is an error when the index asks for it
 
     def precomputed_index_wrapper(self, embed_data=None):
         if embed_data is None:

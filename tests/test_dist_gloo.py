@@ -216,8 +216,6 @@ def _load_worker(rank, world, port, path, log_path):
         fresh = ei.OpenRetreivalDataStore(path, load_from_path=False, rank=0)
         fresh.add_block_data(ids.tolist(), rows)
         fresh._write(path)
-        t = os.path.getmtime(ei.OpenRetreivalDataStore(path, load_from_path=False).flat_path()) + 5
-        os.utime(path, (t, t))
     dist.barrier()
     index.update_index()
     expect(index, 2, 777)
