@@ -99,4 +99,24 @@ def test_config2_step_at_benchmark_shape_ids_layouts_gradients_and_bit_reproduci
     assert abs(lm_p - lm_d) < 1e-3 * max(1.0, abs(lm_d)) and abs(rl_p - rl_d) < 1e-3 * max(1.0, abs(rl_d)), (lm_p, lm_d, rl_p, rl_d)
     rel = float((gp - gd).double().norm() / gd.double().norm())
     assert rel < 2e-2, rel
+    del gd
+
+    # (5) r05: the benchmark's default step -- 4 groups of 16 questions, every activation kept, NO layer re-run (EMDR2Model.forward_backward) --
+    # against the undivided step with the reference's full per-layer recompute, same batch, same parameters, dropout 0: same losses, same
+    # gradients (a re-run layer rebuilds bit-identical activations, so what differs is the order of fp32 additions of the weight gradients)
+    for stack in (model.language_model.language_model.encoder, model.language_model.language_model.decoder,
+                  model.retriever_model.query_model.language_model.encoder, model.retriever_model.context_model.language_model.encoder):
+        stack.checkpoint_activations = False
+    torch.cuda.empty_cache()
+    opt.zero_grad()
+    K.RECOMPUTE.flops = 0.0
+    loss4, stats4 = model.forward_backward(bt["uid"], bt["q"], bt["types"], None, bt["q"], bt["qlen"], bt["dec"], bt["labels"], bt["mask"], 30523,
+                                           micro_batches=4)
+    opt.finish()
+    torch.cuda.synchronize()
+    assert K.RECOMPUTE.flops == 0.0
+    g4 = torch.cat([b["grad"].reshape(-1) for b in opt.buckets])
+    assert abs(float(stats4["lm_loss"]) - lm_p) < 1e-5 * abs(lm_p) and abs(float(stats4["retriever_loss"]) - rl_p) < 1e-5 * abs(rl_p), (float(stats4["lm_loss"]), lm_p)
+    rel = float((g4 - gp).double().norm() / gp.double().norm())
+    assert rel < 1e-4, rel
     K.GRAD_SINK = None
