@@ -196,3 +196,33 @@ def test_retention_guard_reruns_then_thins_the_plan_in_a_fixed_order():
     with pytest.raises(torch.cuda.OutOfMemoryError):
         g.run(step)
     assert m.sel == (0, 0, 0)
+
+
+def test_retention_guard_splits_the_step_finer_when_there_is_no_plan_to_thin():
+    """r05: with question micro-batches nothing is re-run and nothing can be thinned: a step that still runs out of HBM is re-run once as it
+    is, then with twice the groups (as long as they divide the batch), by the same rule on every rank; the step function reads `guard.micro`."""
+    from emdr2_amd.training import RetentionGuard
+
+    class Model:
+        def set_recompute_keep_last(self, n): pass
+        def set_selective_retention(self, r, c=0, q=0): pass
+
+    class Opt:
+        def zero_grad(self): pass
+        def abort_step(self): pass
+    g = RetentionGuard(Model(), Opt(), micro=4, batch=64)
+    seen, fails = [], [3]
+
+    def step():
+        seen.append(g.micro)
+        if fails[0] > 0:
+            fails[0] -= 1
+            raise torch.cuda.OutOfMemoryError("injected")
+        return "ok"
+    assert g.run(step) == "ok"
+    assert seen == [4, 4, 8, 16] and g.reruns == 3 and g.plan["thinned"] == 2
+    g2 = RetentionGuard(Model(), Opt(), micro=4, batch=12)               # 12 questions: 8 groups do not divide them
+    fails[0] = 99
+    with pytest.raises(torch.cuda.OutOfMemoryError):
+        g2.run(step)
+    assert g2.micro == 4
