@@ -348,8 +348,10 @@ class HipIndexShard(object):
         dist = torch.empty((nq, k), dtype=torch.float16, device=self.device)
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
         row = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        # (the search's init launch clears the flags of all nq queries: no fill launch of their own)
+        flags = torch.empty((nq,), dtype=torch.int32, device=self.device)
         if self.n_rows == 0:
+            flags.zero_()
             dist.fill_(float('-inf')); idx.fill_(-1); row.fill_(-1)
             return dist, idx, row, flags
         ws = self._workspace(k)
@@ -379,8 +381,10 @@ class HipIndexShard(object):
         rec = out if out is not None else torch.empty((nq, k, 16), dtype=torch.uint8, device=self.device)
         if rec.shape != (nq, k, 16) or rec.dtype != torch.uint8 or not rec.is_contiguous():
             raise ValueError("records buffer must be a contiguous uint8 [Q, k, 16] tensor")
-        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        # (the search's init launch clears the flags of all nq queries: no fill launch of their own)
+        flags = torch.empty((nq,), dtype=torch.int32, device=self.device)
         if self.n_rows == 0:
+            flags.zero_()
             rec.view(torch.int32).copy_(torch.tensor([-1, -1, -1, 0xff800000 - (1 << 32) if f32 else 0xfc00], dtype=torch.int32, device=self.device))
             return rec, flags
         ws = self._workspace(k)
@@ -430,8 +434,10 @@ class HipIndexShard(object):
         dist = torch.empty((nq, k), dtype=torch.float32, device=self.device)
         idx = torch.empty((nq, k), dtype=torch.int32, device=self.device)
         row = torch.empty((nq, k), dtype=torch.int64, device=self.device)
-        flags = torch.zeros((nq,), dtype=torch.int32, device=self.device)
+        # (the search's init launch clears the flags of all nq queries: no fill launch of their own)
+        flags = torch.empty((nq,), dtype=torch.int32, device=self.device)
         if self.n_rows == 0:
+            flags.zero_()
             dist.fill_(float('-inf')); idx.fill_(-1); row.fill_(-1)
             return dist, idx, row, flags
         ws = self._workspace(k)
