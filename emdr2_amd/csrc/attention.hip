@@ -95,7 +95,21 @@ __global__ void __launch_bounds__(NW * 64, (DROP && CAUSAL) ? 3 : 4) attention_f
     long long stat0 = ((long long)b * p.heads + n) * p.sq;
     if (p.cu_q) { const int c0 = p.cu_q[b]; sq = p.cu_q[b + 1] - c0; qrow0 = c0; q_off = (long long)c0 * p.q_ss; stat0 = (long long)n * p.tq + c0; }
     if (p.cu_k) { const int c0 = p.cu_k[b]; sk = p.cu_k[b + 1] - c0; krow0 = c0; k_off = (long long)c0 * p.k_ss; v_off = (long long)c0 * p.v_ss; }
-    if (qblk * QB >= sq || sk < 1) return;                                        // (packed: a block past the end of a short sequence)
+    if (qblk * QB >= sq) return;                                                  // (packed: a block past the end of a short sequence)
+    if (sk < 1) {
+        // a key sequence without keys: the unsplit launch leaves o / m / l untouched.  A split launch's combine kernel reads EVERY split's
+        // slot of the (uninitialised) workspace: leave the "empty range" partial (-3e38, 0, 0) there; with all ranges empty the combine
+        // kernel finds L == 0 and leaves the row untouched as well
+        const int qz = qblk * QB + wave * QW + l31;
+        if (p.ksplit > 1 && qz < sq) {
+            const long long si = (long long)split * p.stat_n + stat0 + qz;
+            float4 *z = (float4 *)(p.part_o + si * 64 + 32 * hi);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (hi == 0) { p.part_m[si] = -3.0e38f; p.part_l[si] = 0.f; }
+        }
+        return;
+    }
     const int q0 = qblk * QB + wave * QW;
     const int qi = q0 + l31;                       // this lane's query
     const bool qvalid = qi < sq;
@@ -338,6 +352,7 @@ __global__ void __launch_bounds__(256) attention_combine_kernel(AttnParams p, fl
         acc += w * p.part_o[i * 64 + d];
     }
     // si = (b * heads + n) * sq + q  ->  o row (b * sq + q) * heads + n
+    if (!(L > 0.f)) return;                                                      // a sequence without keys: untouched, like the unsplit launch
     const long long bn = si / p.sq, q = si - bn * p.sq, b = bn / p.heads, n = bn - b * p.heads;
     ((__bf16 *)p.o)[((b * p.sq + q) * p.heads + n) * 64 + d] = (__bf16)(acc * (keep_scale / L));
     if (d == 0 && p.m) { p.m[si] = M * 0.6931471805599453f; p.l[si] = L; }

@@ -98,7 +98,18 @@ __global__ void __launch_bounds__(BNW * 64, 3) attention_bwd_dq_kernel(BwdParams
     if (!attn_decode(p.ksplit > 1 ? (int)(blockIdx.x - split * p.base_grid) : (int)blockIdx.x, (p.sq + BNW * 32 - 1) / (BNW * 32), p.batch * p.heads, p.heads, qblk, b, n)) return;
     const SeqExtent ex = seq_extent(p, b, n);
     const int sq = ex.sq, sk = ex.sk;
-    if (qblk * (BNW * 32) >= sq || sk < 1) return;
+    if (qblk * (BNW * 32) >= sq) return;
+    if (sk < 1) {
+        // a key sequence without keys: the unsplit launch leaves dq untouched; a split launch's combine kernel sums EVERY split's slot of
+        // the (uninitialised) partials workspace, so the slots of this workgroup's rows must hold zeros
+        const int qz = qblk * (BNW * 32) + wave * 32 + l31;
+        if (p.ksplit > 1 && qz < sq) {
+            float4 *z = (float4 *)(p.part_dq + ((long long)split * p.stat_n + ex.stat0 + qz) * 64 + 32 * hi);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) z[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        return;
+    }
     const int q0 = qblk * (BNW * 32) + wave * 32;
     const int qi = q0 + l31;
     const bool qvalid = qi < sq;

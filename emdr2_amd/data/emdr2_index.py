@@ -57,8 +57,12 @@ class OpenRetreivalDataStore(object):
             return pickle.load(fh)['embed_data']
 
     def _write(self, path):
-        with open(path, 'wb') as fh:
+        # tmp + rename: a reader -- the trainers' `update_index()`, which stamps the file by size + mtime (ensure_flat_embedding_file) -- can
+        # never see a half-written pickle of an indexer job that is still running
+        tmp = '%s.tmp.%d' % (path, os.getpid())
+        with open(tmp, 'wb') as fh:
             pickle.dump(self.state(), fh)
+        os.replace(tmp, path)
 
     def _shard_path(self, rank):
         return os.path.join(self.temp_dir_name, '%d.pkl' % rank)
@@ -134,7 +138,7 @@ class OpenRetreivalDataStore(object):
 
     def flat_path(self):
         """Where the flat twin of `embedding_path` lives (FlatEmbeddingFile; written by `ensure_flat_embedding_file`)."""
-        return os.path.splitext(self.embedding_path)[0] + '.flat'
+        return flat_twin_path(self.embedding_path)
 
 
 # ---- flat evidence-embedding file (SURVEY 8f-2) --------------------------------------------------------------------------------
@@ -203,42 +207,89 @@ class FlatEmbeddingFile(object):
         return store
 
 
-def ensure_flat_embedding_file(embedding_path, process_group=None, log=None):
-    """The flat twin of the `--embedding-path` pickle, converted ONCE per (re)load by the first rank and memory-mapped by all.
+def _node_first_rank(process_group=None):
+    """True on the rank that does a node's file work -- the reference's `mpu.get_node_first_rank()` role (emdr2_model.py:414-423).  One
+    process per GPU under torch.distributed.run: LOCAL_RANK 0 of every node; without a launcher's environment: rank 0 of the group."""
+    dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
+    if "LOCAL_RANK" in os.environ and dist_on:
+        return int(os.environ["LOCAL_RANK"]) == 0
+    return (torch.distributed.get_rank(process_group) if dist_on else 0) == 0
+
+
+def flat_twin_path(embedding_path, cache_dir=None):
+    """`<embedding_path minus extension>.flat`, or the same file name under `cache_dir` (argument, else $EMDR2_FLAT_CACHE_DIR): a node-local
+    writable directory for installations whose embedding directory is read-only to the trainers (the reference needs only read access)."""
+    cache_dir = cache_dir or os.environ.get("EMDR2_FLAT_CACHE_DIR")
+    flat = os.path.splitext(embedding_path)[0] + '.flat'
+    if cache_dir:
+        os.makedirs(cache_dir, exist_ok=True)
+        flat = os.path.join(cache_dir, os.path.basename(flat))
+    return flat
+
+
+def ensure_flat_embedding_file(embedding_path, process_group=None, log=None, cache_dir=None):
+    """The flat twin of the `--embedding-path` pickle, converted ONCE per (re)load and memory-mapped by all.
 
     The reference unpickles the 32 GB store on the node-first rank only (emdr2_model.py:414-423) and that rank uploads every device's chunk.
     With one process per GPU every rank needs ITS rows; letting each of 8 ranks unpickle 21M small arrays and densify them costs 8 x (40 + 32)
-    GB of host memory and minutes, at start-up and at every `update_index()`.  Here rank 0 of the group converts the pickle to
-    `<path minus extension>.flat` if that file is missing or older than the pickle, everybody meets at a barrier, and each rank then maps the
-    file and touches only its own row range (`DistributedBruteForceIndex.add_flat_file`).  Returns the flat file's path."""
+    GB of host memory and minutes, at start-up and at every `update_index()`.  Here the FIRST RANK OF EVERY NODE (the reference's loader
+    rank) converts the pickle to its flat twin if that file is missing or was made from another pickle, everybody meets at a barrier, and
+    each rank then maps the file and touches only its own row range (`DistributedBruteForceIndex.add_flat_file`).  On a shared file system
+    the nodes write the same bytes to private temporary files and rename them onto the one name (atomic; last writer wins, identical
+    content); with `cache_dir` / $EMDR2_FLAT_CACHE_DIR the twin lives in a node-local writable directory and the embedding directory is
+    only read.  A rank that finds no twin after the barrier (no node-first rank on its node reached it) converts for itself.  The pickle is
+    stamped by size + mtime before AND after the conversion: a pickle replaced meanwhile (indexer jobs write tmp + rename) is converted again.
+    Returns the flat file's path."""
     dist_on = torch.distributed.is_available() and torch.distributed.is_initialized()
-    rank = torch.distributed.get_rank(process_group) if dist_on else 0
-    flat = os.path.splitext(embedding_path)[0] + '.flat'
-    err = None
-    if rank == 0:
+    flat = flat_twin_path(embedding_path, cache_dir)
+    side = flat + '.src'
+
+    def stamp_of():
+        st = os.stat(embedding_path)
+        return "%d %d" % (st.st_size, st.st_mtime_ns)
+
+    def fresh():
+        # the twin remembers WHICH pickle it was made from (size + modification time in ns, in a sidecar): a pickle rewritten by a new
+        # indexer job -- even within the same second -- makes it stale; an unchanged one is never converted twice
         try:
-            # the twin remembers WHICH pickle it was made from (size + modification time in ns, in a sidecar): a pickle rewritten by a new
-            # indexer job -- even within the same second -- makes it stale; an unchanged one is never converted twice
-            st = os.stat(embedding_path)
-            stamp = "%d %d" % (st.st_size, st.st_mtime_ns)
-            side = flat + '.src'
-            stale = not (os.path.exists(flat) and os.path.exists(side) and open(side).read().strip() == stamp)
-            if stale:
-                store = OpenRetreivalDataStore(embedding_path, load_from_path=True, rank=0)
-                FlatEmbeddingFile.from_store(store, flat)
-                with open(side, 'w') as fh:
-                    fh.write(stamp)
-                if log:
-                    log("converted %s (%d embeddings) to %s" % (embedding_path, len(store.embed_data), flat))
-                store.clear()
+            with open(side) as fh:
+                return os.path.exists(flat) and fh.read().strip() == stamp_of()
+        except OSError:
+            return False
+
+    def convert():
+        for _ in range(3):
+            stamp = stamp_of()
+            store = OpenRetreivalDataStore(embedding_path, load_from_path=True, rank=0)
+            FlatEmbeddingFile.from_store(store, flat)
+            n = len(store.embed_data)
+            store.clear()
+            if stamp_of() != stamp:
+                continue                                          # replaced while it was being read: what was converted is already old
+            tmp = '%s.tmp.%d' % (side, os.getpid())
+            with open(tmp, 'w') as fh:
+                fh.write(stamp)
+            os.replace(tmp, side)
+            if log:
+                log("converted %s (%d embeddings) to %s" % (embedding_path, n, flat))
+            return
+        raise RuntimeError("%s kept changing while it was converted" % embedding_path)
+
+    err = None
+    if _node_first_rank(process_group):
+        try:
+            if not fresh():
+                convert()
         except Exception as exc:                                   # the peers are waiting at the barrier: meet them first, then raise
             err = exc
     if dist_on:
         torch.distributed.barrier(process_group)
     if err is not None:
         raise err
-    if not os.path.exists(flat):
-        raise RuntimeError("flat embedding file %s was not produced by rank 0" % flat)
+    if not fresh():
+        # a node whose first rank is not in this group / a twin directory that is not shared: convert here (what every rank of the reference's
+        # one-process-per-node layout would have had to do); a missing pickle raises FileNotFoundError as an eager load would
+        convert()
     return flat
 
 
@@ -550,8 +601,10 @@ class DistributedBruteForceIndex(object):
     def _set_mips_index(self):
         if self.embed_data is not None:
             path = getattr(self.embed_data, "embedding_path", None)
-            if not self.embed_data.embed_data and path and not os.path.exists(path) and getattr(self.embed_data, "_lazy", False):
-                raise FileNotFoundError("evidence embeddings not found: %s" % path)     # (what an eager load would have said)
+            if not self.embed_data.embed_data and path and not os.path.exists(path):
+                # an empty store whose file is missing -- whether it was handed over unloaded or emptied by `update_index()`: what an eager
+                # load would have said, not "rows must be float16 [N, D]" from an index over nothing
+                raise FileNotFoundError("evidence embeddings not found: %s" % path)
             if not self.embed_data.embed_data and path and os.path.exists(path):
                 # a store that has not been loaded (load_from_path=False): go through the flat twin of its file -- rank 0 converts, every
                 # rank maps its own rows; no rank but the first ever unpickles

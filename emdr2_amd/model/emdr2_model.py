@@ -266,11 +266,14 @@ class EMDR2Model(torch.nn.Module):
         What it buys: the activations alive at any time are those of B / m questions, so NO layer has to be re-run in the backward
         (--checkpoint-activations off: zero recompute) inside 288 GB even at top-k 100.  Dropout: group i draws its masks from seeds
         hashed with i (kernels.DROPOUT.micro), so an undivided step (m = 1) is bit-identical to `forward` + `emdr2_loss` + `backward`.
+        B need not be a multiple of `micro_batches` (the short last batch of an epoch under --keep-last, train_e2eqa.py:272): the groups are
+        then `torch.tensor_split`-sized (the first B % m groups hold one question more; fewer groups than asked when B < m) -- the
+        batch-wide denominators make uneven groups exactly as right as even ones.
         `on_group(i)`: called between group i's forward and its backward (test hook: injected allocation failures)."""
         B = query_ids_bert.shape[0]
         m = int(micro_batches)
-        if m < 1 or B % m:
-            raise ValueError("micro_batches must divide the batch (%d questions, %d groups)" % (B, m))
+        if m < 1:
+            raise ValueError("micro_batches must be >= 1 (got %d)" % m)
         if not self.training:
             raise ValueError("forward_backward is a training-mode call")
         totals = loss_totals(labels, loss_mask, eos_id)
@@ -282,12 +285,11 @@ class EMDR2Model(torch.nn.Module):
                 query_logits.detach(), query_uid, query_ids_t5, query_ids_t5_len, self.cls_id, self.sep_id, self.pad_id)
         Kk = ctx_ids.shape[1]
         q_leaf = query_logits.detach().requires_grad_(query_logits.requires_grad)
-        g = B // m
+        bounds = question_group_bounds(B, m)
         loss_sum, stats_sum = None, {}
         try:
-            for i in range(m):
+            for i, (lo, hi) in enumerate(bounds):
                 K.DROPOUT.micro = i
-                lo, hi = i * g, (i + 1) * g
                 lm, tlp, one = self.forward_assembled(q_leaf[lo:hi], ctx_ids[lo:hi], ctx_types[lo:hi], qext[lo * Kk:hi * Kk], qone[lo * Kk:hi * Kk],
                                                       dec_ids[lo:hi])
                 loss, stats = emdr2_loss(lm, tlp, one, labels[lo:hi], loss_mask[lo:hi], eos_id, ret_kldiv=ret_kldiv, totals=totals)
@@ -348,6 +350,20 @@ class EMDR2Model(torch.nn.Module):
             return
         checkpointing.load_t5_checkpoint(self.language_model, pretrained_t5_load)
         checkpointing.load_dualencoder_checkpoint(self.retriever_model, pretrained_dpr_load)
+
+
+def question_group_bounds(batch, micro_batches):
+    """[(lo, hi)] of the question groups of a step: min(micro_batches, batch) groups, sizes as `torch.tensor_split` deals them (the first
+    batch % m groups get one question more).  The same function of (batch, m) on every rank: the number of gradient contributions per
+    parameter -- what FlatAdam's bucket protocol counts -- follows from it."""
+    m = max(1, min(int(micro_batches), int(batch)))
+    base, extra = divmod(int(batch), m)
+    bounds, lo = [], 0
+    for i in range(m):
+        hi = lo + base + (1 if i < extra else 0)
+        bounds.append((lo, hi))
+        lo = hi
+    return bounds
 
 
 def loss_totals(labels, loss_mask, eos_id):

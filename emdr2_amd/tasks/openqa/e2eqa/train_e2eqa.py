@@ -43,8 +43,9 @@ def _cross_entropy_forward_step(batch, model, eos_id):
 
 def train_step(forward_step_func, data_iterator, model, optimizer, lr_scheduler, eos_id, dp_group=None, guard=None):
     """megatron/training.py:202-230 without the fp16 machinery (bf16 needs no loss scale / overflow skip).  `guard` (training.RetentionGuard,
-    built when --recompute-keep-last-layers / --selective-retention-layers ask for activations to be kept): a step that runs out of HBM is
-    run again on all ranks together, with a thinner retention plan if need be, instead of ending the job."""
+    built when --recompute-keep-last-layers / --selective-retention-layers ask for activations to be kept or --question-micro-batches
+    splits the step): a step that runs out of HBM is run again on all ranks together, with a thinner retention plan / a finer split if
+    need be, instead of ending the job."""
     from emdr2_amd.model import kernels
     try:
         batch = next(data_iterator)                  # fetched once: a re-run of the step sees the same batch
@@ -209,11 +210,16 @@ def _train(model, optimizer, lr_scheduler, forward_step, train_dataloader, end_o
     guard = None
     sel = [int(v) for v in str(getattr(args, "selective_retention_layers", "0,0,0")).split(",")] + [0, 0, 0]
     keep = int(getattr(args, "recompute_keep_last_layers", 0) or 0)
-    if keep or any(sel[:3]):
+    micro = int(getattr(args, "question_micro_batches", 1) or 1)
+    if keep or any(sel[:3]) or micro > 1:
         from emdr2_amd.training import RetentionGuard
         retr = getattr(model, "evidence_retriever", None)
+
+        def set_micro(m):                             # _cross_entropy_forward_step reads the flag: a finer split after an allocation failure
+            args.question_micro_batches = m           # takes effect in the re-run of the very step that failed
         guard = RetentionGuard(model, optimizer, keep=keep, reader=sel[0], context=sel[1], query=sel[2],
-                               forward_progress=(lambda: getattr(retr, "searches", 0)) if retr is not None else None, log=print_rank_0)
+                               forward_progress=(lambda: getattr(retr, "searches", 0)) if retr is not None else None, log=print_rank_0,
+                               micro=micro, batch=args.batch_size, on_micro_change=set_micro)
     start_epoch = args.iteration // args.train_iters_per_epoch
     start_iteration = args.iteration % args.train_iters_per_epoch
     iteration = args.iteration

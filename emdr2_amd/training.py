@@ -452,12 +452,15 @@ class RetentionGuard(object):
     behind this rank -- before that point of an attempt its peers cannot be told and the failure is raised.  Used by bench_e2e.py and by
     the training task."""
 
-    def __init__(self, model, optimizer, keep=0, reader=0, context=0, query=0, forward_progress=None, log=None, micro=1, batch=None):
+    def __init__(self, model, optimizer, keep=0, reader=0, context=0, query=0, forward_progress=None, log=None, micro=1, batch=None,
+                 on_micro_change=None):
         self.model, self.opt = model, optimizer
         self.plan = {"keep": int(keep), "reader": int(reader), "context": int(context), "query": int(query), "thinned": 0}
         # question micro-batches of a step (EMDR2Model.forward_backward; the step function reads `guard.micro`): with m > 1 nothing is
-        # re-run and there is no retention plan to thin -- a step that still does not fit is split finer (m doubles while it divides the batch)
-        self.micro, self.batch = max(1, int(micro)), batch
+        # re-run and there is no retention plan to thin -- a step that still does not fit is split finer (m doubles, up to one question per
+        # group: forward_backward takes group counts that do not divide the batch).  `on_micro_change(m)`: how a step function that reads the
+        # group count from somewhere else (the task's --question-micro-batches flag) is told
+        self.micro, self.batch, self.on_micro_change = max(1, int(micro)), batch, on_micro_change
         self.reruns = 0
         self.forward_progress = forward_progress
         self.log = log or (lambda msg: None)
@@ -483,8 +486,10 @@ class RetentionGuard(object):
             p["keep"] -= 1
         elif p["reader"] > 0:
             p["reader"] = max(0, p["reader"] - 2)
-        elif self.micro > 1 and self.batch and self.batch % (2 * self.micro) == 0:
-            self.micro *= 2
+        elif self.micro > 1 and self.batch and self.micro < self.batch:
+            self.micro = min(2 * self.micro, int(self.batch))
+            if self.on_micro_change is not None:
+                self.on_micro_change(self.micro)
             p["thinned"] += 1
             self.log("step split into %d question micro-batches after an allocation failure" % self.micro)
             return True

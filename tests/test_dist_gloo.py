@@ -7,6 +7,7 @@ import socket
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -258,3 +259,40 @@ def test_store_to_arrays_and_flat_file_are_block_gathers_of_the_dict(tmp_path):
     assert np.array_equal(i2, ids) and np.array_equal(r2.view(np.uint16), rows.view(np.uint16))
     flat = FlatEmbeddingFile.from_store(store, str(tmp_path / "e.flat"))
     assert np.array_equal(flat.ids, ids) and np.array_equal(np.asarray(flat.rows).view(np.uint16), rows.view(np.uint16))
+
+
+def test_flat_twin_in_a_cache_directory_and_a_missing_pickle(tmp_path, monkeypatch):
+    """(a) with $EMDR2_FLAT_CACHE_DIR the flat twin and its sidecar live in a node-local writable directory -- nothing is
+    written next to the pickle (the reference needs only read access to --embedding-path); (b) `update_index()` / a construction over an
+    empty store whose pickle is missing raises FileNotFoundError (what an eager load would have said), whether or not the store was
+    marked lazy; (c) the store's own writes are tmp + rename: no partial file is ever visible under the final name."""
+    from emdr2_amd.data import emdr2_index as ei
+
+    class Index(ei.DistributedBruteForceIndex):
+        def _make_shard(self, dim, n, base):
+            return _OracleShard(dim, n, base)
+
+    emb_dir, cache = tmp_path / "emb", tmp_path / "cache"
+    emb_dir.mkdir()
+    path = str(emb_dir / "e.pkl")
+    rng = np.random.default_rng(3)
+    rows = rng.standard_normal((300, 64)).astype(np.float16)
+    ids = (rng.permutation(300) + 1).astype(np.int32)
+    store = ei.OpenRetreivalDataStore(path, load_from_path=False, rank=0)
+    store.add_block_data(ids.tolist(), rows)
+    seen = []
+    real_replace = os.replace
+    monkeypatch.setattr(os, "replace", lambda a, b: (seen.append((os.path.basename(a), os.path.basename(b))), real_replace(a, b))[1])
+    store._write(path)
+    assert seen and seen[0][1] == "e.pkl" and seen[0][0].startswith("e.pkl.tmp.")          # (c)
+    monkeypatch.setenv("EMDR2_FLAT_CACHE_DIR", str(cache))
+    unloaded = ei.OpenRetreivalDataStore(path, load_from_path=False, rank=0)
+    index = Index(embed_size=64, embed_data=unloaded, use_gpu=True)
+    assert sorted(os.listdir(str(emb_dir))) == ["e.pkl"]                                    # (a) the embedding directory was only read
+    assert sorted(os.listdir(str(cache))) == ["e.flat", "e.flat.src"]
+    assert np.array_equal(index.shard.ids, ids) and unloaded.flat_path() == str(cache / "e.flat")
+    os.remove(path)
+    with pytest.raises(FileNotFoundError):                                                  # (b) a user-supplied store, never marked lazy
+        index.update_index()
+    with pytest.raises(FileNotFoundError):
+        Index(embed_size=64, embed_data=ei.OpenRetreivalDataStore(path, load_from_path=False, rank=0), use_gpu=True)

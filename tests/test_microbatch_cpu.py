@@ -75,3 +75,17 @@ def test_groups_of_questions_reproduce_the_reference_loss_and_gradients(kldiv):
         assert set(grads) == set(g_ref)
         for k in g_ref:
             assert float((grads[k] - g_ref[k]).abs().max()) <= 1e-5 * float(g_ref[k].abs().max()) + 1e-7, (groups, k)
+
+
+def test_question_group_bounds_cover_any_batch():
+    """a batch the group count does not divide (the short last batch of an epoch under --keep-last) is split like
+    `torch.tensor_split`; more groups than questions degrade to one question per group."""
+    import torch
+    from emdr2_amd.model.emdr2_model import question_group_bounds
+    for batch in range(1, 20):
+        for m in range(1, 12):
+            b = question_group_bounds(batch, m)
+            assert len(b) == min(m, batch) and b[0][0] == 0 and b[-1][1] == batch
+            assert all(b[i][1] == b[i + 1][0] for i in range(len(b) - 1))
+            sizes = [hi - lo for lo, hi in b]
+            assert sizes == [t.numel() for t in torch.tensor_split(torch.arange(batch), min(m, batch))]

@@ -262,6 +262,52 @@ def test_split_key_launches_equal_the_unsplit_launch(drop_p):
         assert torch.equal(o3, o2) and torch.equal(dq3, dq2)
 
 
+def test_split_key_launch_with_a_key_sequence_that_has_no_keys():
+    """a packed key sequence of ZERO keys (only a direct caller of the C ABI can build one: cu_k[b] == cu_k[b + 1]).  The
+    unsplit launch leaves that question's output / dQ rows untouched; the split launch's combine kernels sum every split's slot of an
+    uninitialised workspace, so the early-return path must leave defined partials there: the other questions' results equal the unsplit
+    launch's, the keyless question's output is untouched and its dQ zero, nothing is NaN, dK / dV are unaffected."""
+    from emdr2_amd.model import kernels as K
+    rng = np.random.default_rng(5)
+    B, Kk, S, L, heads = 3, 50, 512, 32, 2
+    ids, _ = _ragged_ids(rng, B * Kk, S, 500, lo=S // 4)
+    ids_t = torch.from_numpy(ids).cuda()
+    dec, _ = _ragged_ids(rng, B, L, 500, lo=2)
+    dec_t = torch.from_numpy(dec).cuda()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    q = torch.randn((B, L, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    seqs = K.PackedSeqs(ids_t)
+    gk = seqs.grouped(Kk)
+    cu = gk.cu.clone()
+    cu[1] = cu[2]                                                        # question 1: no keys; question 0 takes its passages as well
+    gk.cu, gk.max_len = cu.contiguous(), 2 * S * Kk
+    kv = torch.randn((seqs.rows, 2, heads, 64), generator=g, device="cuda").bfloat16().requires_grad_(True)
+    w = torch.randn((B, L, heads, 64), generator=g, device="cuda")
+    w[1] = 0
+
+    def run(force_unsplit):
+        K._SPLITKV_PLANS.clear()
+        plan = K._splitkv_plan(B, heads, L, gk.max_len)
+        assert plan[0] > 1, plan
+        if force_unsplit:
+            K._SPLITKV_PLANS[(B, heads, L, gk.max_len)] = (1, 0, 0)
+        q.grad = kv.grad = None
+        # poison what torch.empty would hand out next: a path that reads uninitialised workspace sees NaNs
+        junk = torch.full((64 << 20,), float("nan"), device="cuda"); del junk
+        out = K.attention_core(q, kv, dec_t, gk, False, drop_p=0.0, seed=1)
+        (out.float() * w).sum().backward()
+        K._SPLITKV_PLANS.clear()
+        return out.detach().clone(), q.grad.clone(), kv.grad.clone()
+
+    o1, dq1, dkv1 = run(True)
+    o2, dq2, dkv2 = run(False)
+    for i in (0, 2):
+        assert bool(torch.isfinite(o2[i].float()).all()) and _rel(o2[i], o1[i]) < 8e-3
+        assert bool(torch.isfinite(dq2[i].float()).all()) and _rel(dq2[i], dq1[i]) < 1e-2
+    assert float(dq2[1].float().abs().max()) == 0.0                       # zero partials, folded: no gradient for a question without keys
+    assert bool(torch.isfinite(dkv2.float()).all()) and _rel(dkv2, dkv1) < 1e-2
+
+
 def test_packed_attention_dropout_mask_exact_at_block_boundaries():
     """Dropout on the packed launch, element by element: the keep bit of (head n, packed row r, key k of r's sequence) is the site hash at
     (row n * rows + r, column k) -- the same generator as every other dropout site -- so a torch reference with that mask pins forward, dq

@@ -200,7 +200,8 @@ def test_retention_guard_reruns_then_thins_the_plan_in_a_fixed_order():
 
 def test_retention_guard_splits_the_step_finer_when_there_is_no_plan_to_thin():
     """r05: with question micro-batches nothing is re-run and nothing can be thinned: a step that still runs out of HBM is re-run once as it
-    is, then with twice the groups (as long as they divide the batch), by the same rule on every rank; the step function reads `guard.micro`."""
+    is, then with twice the groups (up to one question per group: r06, the groups need not divide the batch), by the same rule on every rank;
+    the step function reads `guard.micro` or is told through `on_micro_change` (the task's --question-micro-batches flag)."""
     from emdr2_amd.training import RetentionGuard
 
     class Model:
@@ -221,8 +222,9 @@ def test_retention_guard_splits_the_step_finer_when_there_is_no_plan_to_thin():
         return "ok"
     assert g.run(step) == "ok"
     assert seen == [4, 4, 8, 16] and g.reruns == 3 and g.plan["thinned"] == 2
-    g2 = RetentionGuard(Model(), Opt(), micro=4, batch=12)               # 12 questions: 8 groups do not divide them
+    told = []
+    g2 = RetentionGuard(Model(), Opt(), micro=4, batch=12, on_micro_change=told.append)      # 12 questions: 8 groups do not divide them -- allowed
     fails[0] = 99
     with pytest.raises(torch.cuda.OutOfMemoryError):
         g2.run(step)
-    assert g2.micro == 4
+    assert g2.micro == 12 and told == [8, 12]                            # 4 -> 8 -> 12 (one question per group), then nothing is left to split
