@@ -177,6 +177,16 @@ def clustered_leg(args, rank, world, steps=5):
     return out
 
 
+def result_digest(dist, idx):
+    """sha256 over the (scores fp16 [Q, k], doc ids int32 [Q, k]) a search returned: the canonical result is a function of the index and
+    the queries alone, so the digest of an N-shard run must equal the single-shard run's (tests/test_world8_gpu.py)."""
+    import hashlib
+    h = hashlib.sha256()
+    h.update(dist.detach().to(torch.float16).contiguous().cpu().numpy().tobytes())
+    h.update(idx.detach().to(torch.int32).contiguous().cpu().numpy().tobytes())
+    return h.hexdigest()
+
+
 def cpu_baseline(args, queries_cpu):
     """Reference arithmetic on the host cores: fp32-accumulate GEMM (torch/MKL), one rounding to fp16, top-k --
     oracle.mips_oracle.topk_blas -- over >= 1M synthetic rows, in the metric's unit by scaling rows/s to the full index.
@@ -250,6 +260,12 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
+    digest = result_digest(out[0], out[1])
+    digests_agree = None
+    if world > 1:                                           # every rank must hold the same merged result
+        every = [None] * world
+        torch.distributed.all_gather_object(every, digest)
+        digests_agree = len(set(every)) == 1
 
     # per-launch scan timings recorded with hipEvents on the launch stream during the timed region
     cap = 2048
@@ -343,6 +359,8 @@ def main():
                        "rows": args.rows, "dim": DIM, "queries_per_step": nq, "top_k": k,
                        "parallelism": "index row-sharded x%d, all-gather(top-k) + merge" % world,
                        "cus": int(lib.emdr2_device_cu_count()), "unproven_queries": flags_total,
+                       # scores + doc ids of all queries of the last timed search: equal for any number of shards / ranks
+                       "result_sha256": digest, "result_identical_on_all_ranks": digests_agree,
                        "timed_call": "DistributedBruteForceIndex.search_mips_index (flag read + exact fallback + exchange included)",
                        "inner_sequence_ms_per_step": inner_ms,
                        # what makes the 1 -> N curve interpretable: rows scanned per rank, bytes every rank contributes to the ONE

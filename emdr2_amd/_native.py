@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libemdr2_hip.so")     # tools/ may point this at lib/libemdr2_hip_exp.so (`make exp`) before first use
 
-EMDR2_ABI_VERSION = 3
+EMDR2_ABI_VERSION = 4
 FLAG_AMBIGUOUS = 1
 FLAG_OVERFLOW = 2
 MAX_TOPK = 120
@@ -107,6 +107,25 @@ SIGNATURES["emdr2_marginal_bwd"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, 
 SIGNATURES["emdr2_lse_combine"] = (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp])
 SIGNATURES["emdr2_ops_set_timing"] = (_i32, [_i32])
 SIGNATURES["emdr2_ops_timing_collect"] = (_i32, [ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_i64), _i32])
+
+
+# include/emdr2_ops_f32.h (ABI 4): the validation-only fp32 compute path
+SIGNATURES.update({
+    "emdr2_f32_gemm": (_i32, [_vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, _f32,
+                              _vp, _vp, _i32, _vp]),
+    "emdr2_f32_layernorm_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "emdr2_f32_layernorm_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_f32_softmax_mask_fwd": (_i32, [_vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "emdr2_f32_softmax_mask_bwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "emdr2_f32_gelu_fwd": (_i32, [_vp, _vp, _i64, _vp]),
+    "emdr2_f32_gelu_bwd": (_i32, [_vp, _vp, _vp, _i64, _vp]),
+    "emdr2_f32_embedding_fwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "emdr2_f32_embedding_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "emdr2_f32_lse_gather_fwd": (_i32, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_f32_lse_gather_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "emdr2_f32_retriever_prior_fwd": (_i32, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+    "emdr2_f32_retriever_prior_bwd": (_i32, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _f32, _vp]),
+})
 
 
 class EvidenceArenaStruct(ctypes.Structure):

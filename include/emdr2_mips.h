@@ -33,7 +33,7 @@
 extern "C" {
 #endif
 
-#define EMDR2_ABI_VERSION 3
+#define EMDR2_ABI_VERSION 4
 
 #define EMDR2_OK 0
 #define EMDR2_E_BADARG (-1)      /* bad size / alignment / null pointer */

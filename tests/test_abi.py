@@ -38,7 +38,7 @@ def test_every_declared_symbol_is_exported_and_bound(lib):
 
 
 def test_abi_version(lib):
-    assert lib.emdr2_abi_version() == 3          # r05: packed-record search / merge entry points
+    assert lib.emdr2_abi_version() == 4          # r06: the validation-only fp32 compute path (include/emdr2_ops_f32.h); r05: packed records
 
 
 def test_layout_bytes_and_argument_validation(lib):
@@ -112,3 +112,21 @@ def test_r05_entry_points_validate_their_arguments(lib):
     assert plan(16, 12, 32, 4095) == (1, 0, 0) and plan(16, 12, 32, 4096)[0] == 2                       # short key sets never split
     assert plan(16, 12, 129, 25600) == (1, 0, 0) and plan(16, 12, 128, 65536)[0] == 32                 # one query block only
     assert lib.emdr2_attention_splitkv_plan(0, 12, 32, 25600, ctypes.byref(ks), ctypes.byref(fb), ctypes.byref(bb)) == -1
+
+
+def test_fp32_validation_entry_points_validate_their_arguments(lib):
+    """include/emdr2_ops_f32.h (ABI 4): null pointers / empty shapes are refused before any launch."""
+    one = ctypes.c_void_p(4096)
+    assert lib.emdr2_f32_gemm(None, 1, 1, 0, 0, one, 1, 1, 0, 0, one, 1, 1, 0, 0, 4, 4, 4, 1, 1, 1.0, None, None, 0, None) == -1
+    assert lib.emdr2_f32_gemm(one, 1, 1, 0, 0, one, 1, 1, 0, 0, one, 1, 1, 0, 0, 4, 4, 0, 1, 1, 1.0, None, None, 0, None) == -1
+    assert lib.emdr2_f32_layernorm_fwd(one, one, one, one, one, None, 4, 16, 1e-5, None) == -1
+    assert lib.emdr2_f32_layernorm_bwd(one, one, one, one, one, None, one, one, None, 4, 16, None) == -1
+    assert lib.emdr2_f32_softmax_mask_fwd(one, one, None, 1, 1, 4, 4, 0, None) == -1
+    assert lib.emdr2_f32_softmax_mask_bwd(one, None, one, one, 1, 1, 4, 4, 0, None) == -1
+    assert lib.emdr2_f32_gelu_fwd(one, None, 8, None) == -1 and lib.emdr2_f32_gelu_bwd(one, one, one, 0, None) == -1
+    assert lib.emdr2_f32_embedding_fwd(one, None, one, one, one, one, 4, 4, 16, None) == -1      # a token-type table without token types
+    assert lib.emdr2_f32_embedding_bwd(one, None, one, one, None, None, 4, 4, 16, None) == -1
+    assert lib.emdr2_f32_lse_gather_fwd(one, one, one, None, 4, 16, None) == -1
+    assert lib.emdr2_f32_lse_gather_bwd(one, one, one, one, None, 4, 16, None) == -1
+    assert lib.emdr2_f32_retriever_prior_fwd(one, one, one, one, 2, 2000, 16, 1.0, None) == -1    # K <= 1024
+    assert lib.emdr2_f32_retriever_prior_bwd(one, one, one, one, one, None, 2, 4, 16, 1.0, None) == -1

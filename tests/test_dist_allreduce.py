@@ -118,7 +118,7 @@ def test_bucketed_overlapped_gradient_averaging_matches_plain_average(tmp_path):
     assert r0[2][2] > r0[1][2] > 0                                           # later steps launch buckets from inside the "backward"
 
 
-def _abort_worker(rank, world, port, out_dir):
+def _abort_worker(rank, world, port, out_dir, abort_rank=1, late_rank=1):
     sys.path.insert(0, ROOT)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -149,10 +149,10 @@ def _abort_worker(rank, world, port, out_dir):
     for step in range(2):                                                       # learn the pattern, then a step with early launches
         sink.begin_step(); backward(100 * step); sink.finish()
     assert sink.launched_early > 0
-    # step 2: rank 1 "runs out of memory" after two contributions (one bucket has already left); rank 0 completes its backward.
-    # Both must come out of the step with StepAborted / a returned abort_step(), neither may hang
+    # step 2: rank `abort_rank` "runs out of memory" after two contributions (one bucket has already left); the others complete their
+    # backward.  All must come out of the step with StepAborted / a returned abort_step(), none may hang
     sink.begin_step()
-    if rank == 1:
+    if rank == abort_rank:
         backward(200, upto=2)
         sink.abort_step()
         aborted = True
@@ -167,9 +167,9 @@ def _abort_worker(rank, world, port, out_dir):
     # step 3: business as usual -- the plain average again
     sink.begin_step(); c = backward(300); sink.finish()
     record["after_abort"] = ([p.grad.clone() for p in params], [c[i] for i in range(len(params))])
-    # step 4: only rank 1 sees a late second contribution to the first parameter that leaves (pattern disagreement between ranks,
-    # ADVICE r3): rank 0 joins the late-buffer all-reduce with zeros instead of deadlocking rank 1
-    sink.begin_step(); c = backward(400, extra=(4,) if rank == 1 else ()); sink.finish()
+    # step 4: only rank `late_rank` sees a late second contribution to the first parameter that leaves (pattern disagreement between
+    # ranks): the others join the late-buffer all-reduce with zeros instead of deadlocking it
+    sink.begin_step(); c = backward(400, extra=(4,) if rank == late_rank else ()); sink.finish()
     record["late_on_one_rank"] = ([p.grad.clone() for p in params], [c[i] for i in range(len(params))])
     torch.save(record, os.path.join(out_dir, "a%d.pt" % rank))
     K.GRAD_SINK = None
@@ -187,3 +187,40 @@ def test_a_rank_that_gives_a_step_up_takes_its_peers_with_it_and_the_next_step_i
         (g0, c0), (g1, c1) = r0[key], r1[key]
         for a, b, x, y in zip(g0, g1, c0, c1):
             assert torch.allclose(a, b) and torch.allclose(a, (x + y) / 2, atol=1e-6), key
+
+
+def test_abort_and_late_contribution_protocol_at_world_eight(tmp_path):
+    """the same protocol with EIGHT ranks (the world size of BASELINE configs[3] / [4]; the largest any test had started
+    was 3): rank 5 gives a step up in mid-backward, all eight discard it and the next step is the plain average over eight; a late
+    contribution seen by rank 3 only is exchanged by all eight."""
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_abort_worker, args=(world, port, str(tmp_path), 5, 3), nprocs=world, join=True)
+    rec = [torch.load(os.path.join(str(tmp_path), "a%d.pt" % r)) for r in range(world)]
+    for key in ("after_abort", "late_on_one_rank"):
+        grads = [r[key][0] for r in rec]
+        contribs = [r[key][1] for r in rec]
+        for i in range(len(grads[0])):
+            mean = sum(c[i] for c in contribs) / world
+            for g in grads:
+                assert torch.equal(g[i], grads[0][i])                            # every replica received the same averaged gradient
+            assert torch.allclose(grads[0][i], mean, atol=1e-6), key
+
+
+def test_bucketed_gradient_averaging_at_world_eight(tmp_path):
+    """FlatAdam's bucket bookkeeping (learned contribution counts, buckets leaving in index order from inside the backward, a changed
+    pattern) with eight gloo ranks: every rank ends every step with the plain average over the eight."""
+    world = 8
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mp.spawn(_bucket_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    rec = [torch.load(os.path.join(str(tmp_path), "b%d.pt" % r)) for r in range(world)]
+    for step in range(4):
+        for i in range(6):
+            xs = [r[step][1][i] for r in rec]
+            gs = [r[step][0][i] for r in rec]
+            if xs[0] is None:
+                assert all(g is None or float(g.abs().max()) == 0.0 for g in gs)
+                continue
+            mean = sum(xs) / world
+            assert all(torch.equal(g, gs[0]) for g in gs) and torch.allclose(gs[0], mean, atol=1e-6), (step, i)
+    assert rec[0][2][2] > rec[0][1][2] > 0
