@@ -49,6 +49,9 @@ def get_parser():
     g.add_argument('--warmup', type=float, default=0.01)
     g.add_argument('--log-interval', type=int, default=100)
     g.add_argument('--fp16', action='store_true')
+    g.add_argument('--fp32-validation', action='store_true',
+                   help='VALIDATION ONLY: run the model in fp32 on the fp32 matrix cores (the reference\'s arithmetic when --fp16 is not given, '
+                        'megatron/training.py:55-56): slow, dense layouts, dropout must be 0 -- exists so that "logits within 1e-3 fp32" can be tested')
     g.add_argument('--model-parallel-size', type=int, default=1)
     g.add_argument('--distributed-backend', default='nccl')
     g.add_argument('--DDP-impl', default='local')
@@ -137,9 +140,14 @@ def parse_args(argv=None):
     args.iteration = 0
     # the reference's --fp16 (fp16 activations, fp32 masters inside FP16_Optimizer, dynamic loss scaling) maps to this build's ONLY
     # precision mode: bf16 activations and working weights, fp32 master weights and gradients, no loss scaling.  Said once, recorded in args.
-    args.params_dtype = 'bf16'
+    args.compute_dtype = 'fp32' if getattr(args, 'fp32_validation', False) else 'bf16'
+    args.params_dtype = args.compute_dtype
     args.master_dtype = 'fp32'
-    if args.rank == 0:
+    if args.rank == 0 and args.compute_dtype == 'fp32':
+        print("emdr2_amd: --fp32-validation: fp32 activations and weights on the fp32 matrix cores (validation only: slow, dense layouts, no dropout)",
+              flush=True)
+    elif args.rank == 0:
         print("emdr2_amd: %sbf16 activations / working weights with fp32 master weights and fp32 weight gradients; no loss scaling "
-              "(there is no fp16 or fp32 compute mode in this build)" % ("--fp16 requested -> " if args.fp16 else ""), flush=True)
+              "(there is no fp16 compute mode in this build; --fp32-validation runs the slow fp32 validation path)"
+              % ("--fp16 requested -> " if args.fp16 else ""), flush=True)
     return args

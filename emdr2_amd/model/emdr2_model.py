@@ -161,7 +161,7 @@ class EMDR2Model(torch.nn.Module):
             cfg = Config(num_layers=a.num_layers, hidden_size=a.hidden_size, num_attention_heads=a.num_attention_heads,
                          ffn_hidden_size=a.ffn_hidden_size, max_position_embeddings=a.max_position_embeddings,
                          layernorm_epsilon=a.layernorm_epsilon, init_method_std=a.init_method_std, hidden_dropout=a.hidden_dropout,
-                         attention_dropout=a.attention_dropout)
+                         attention_dropout=a.attention_dropout, compute_dtype=getattr(a, "compute_dtype", "bf16"))
             t5_vocab_size, bert_vocab_size = a.t5_padded_vocab_size, a.bert_padded_vocab_size
             topk, seq_length, seq_length_ret = a.topk_retrievals, a.seq_length, a.seq_length_ret
             cls_id, sep_id, pad_id = t5_tok.cls, t5_tok.sep, t5_tok.pad

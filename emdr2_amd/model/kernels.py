@@ -22,6 +22,17 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+def _f32(t):
+    """The validation-only fp32 compute path (kernels_f32.py, include/emdr2_ops_f32.h) is selected by the ACTIVATION dtype: a stack whose
+    embeddings emit fp32 (transformer.Config(compute_dtype="fp32")) runs every op downstream in fp32."""
+    return t is not None and t.dtype == torch.float32
+
+
+def _F32():
+    from emdr2_amd.model import kernels_f32
+    return kernels_f32
+
+
 def _check_bf16(*ts):
     for t in ts:
         if t is not None and (t.dtype != BF16 or not t.is_cuda):
@@ -332,6 +343,8 @@ class FanInFn(torch.autograd.Function):
 
 
 def fan_in(x):
+    if _f32(x):
+        return x                                                  # (fp32 validation path: autograd's own sums)
     return FanInFn.apply(x) if torch.is_grad_enabled() and x.requires_grad else x
 
 
@@ -531,6 +544,8 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, weight, bias=None, gelu=False, residual=None, row_perm=None, drop_p=0.0, seed=0):
+    if _f32(x):
+        return _F32().linear(x, weight, bias, gelu, residual, row_perm, drop_p, seed)
     return LinearFn.apply(x, weight, bias, gelu, residual, row_perm, drop_p, seed, torch.is_grad_enabled())
 
 
@@ -594,6 +609,8 @@ class MLPFn(torch.autograd.Function):
 
 
 def mlp(x, w1, b1, w2, b2, residual, drop_p=0.0, seed=0):
+    if _f32(x):
+        return _F32().mlp(x, w1, b1, w2, b2, residual, drop_p, seed)
     return MLPFn.apply(x, w1, b1, w2, b2, residual, drop_p, seed, torch.is_grad_enabled())
 
 
@@ -795,11 +812,15 @@ def ln_mlp(x, gamma, beta, eps, w1, b1, w2, b2, drop_p=0.0, seed=0):
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
+    if _f32(x):
+        return _F32().layer_norm(x, gamma, beta, eps)
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
 def layer_norm_residual(x, gamma, beta, eps=1e-5):
     """(LayerNorm(x), x): use the second output as the residual operand of the block that consumes the first."""
+    if _f32(x):
+        return _F32().layer_norm_residual(x, gamma, beta, eps)
     return LayerNormFn.apply(x, gamma, beta, eps, True)
 
 
@@ -1016,6 +1037,8 @@ class AttentionCoreFn(torch.autograd.Function):
 
 def attention_core(qsrc, kvsrc, ids_q, ids_k, causal=False, drop_p=0.0, seed=0, site=0):
     """qsrc packed [b, s, 3, np, hn] with kvsrc None (self-attention), or qsrc [b, sq, np, hn] + kvsrc packed [b, sk, 2, np, hn]."""
+    if _f32(qsrc):
+        return _F32().attention_core(qsrc, kvsrc, ids_q, ids_k, causal, drop_p, seed, site)
     return AttentionCoreFn.apply(qsrc, kvsrc, ids_q, ids_k, causal, drop_p, seed, site)
 
 
@@ -1065,8 +1088,11 @@ class EmbeddingFn(torch.autograd.Function):
         return None, None, None, None, None, None, None, None
 
 
-def embedding(ids, types, W, P, T, drop_p=0.0, seed=0, seqs=None):
-    """ids [b, s] (+ types) -> [b, s, H]; or `seqs` = a PackedSeqs -> [rows, H] (ids / types are taken from the layout)."""
+def embedding(ids, types, W, P, T, drop_p=0.0, seed=0, seqs=None, fp32=False):
+    """ids [b, s] (+ types) -> [b, s, H]; or `seqs` = a PackedSeqs -> [rows, H] (ids / types are taken from the layout).
+    `fp32`: emit fp32 activations -- the validation-only fp32 path (kernels_f32.py), which everything downstream then follows."""
+    if fp32:
+        return _F32().embedding(ids, types, W, P, T, drop_p, seed, seqs)
     return EmbeddingFn.apply(ids, types, W, P, T, drop_p, seed, seqs)
 
 
@@ -1099,6 +1125,8 @@ class LseGatherFn(torch.autograd.Function):
 
 
 def lse_gather(logits, labels):
+    if _f32(logits):
+        return _F32().lse_gather(logits, labels)
     return LseGatherFn.apply(logits, labels)
 
 
@@ -1108,6 +1136,8 @@ def lm_head_gold_logprob(hidden, weight, bias, labels):
     block, only (max, sum exp) and the gold logit (csrc/gemm8.hip LSE mode) plus a small combine kernel.  Logits are rounded to bf16 inside
     the epilogue exactly as the unfused path stores them, so both paths agree.  No gradient: this is the no-grad one-context pass
     (emdr2_model.py:185-210), whose [B, K, L, V] logits are 6.3 GB at the benchmark shape."""
+    if _f32(hidden):
+        return _F32().lm_head_gold_logprob(hidden, weight, bias, labels)
     _check_bf16(hidden)
     V, H = weight.shape
     h2 = hidden.reshape(-1, H)
@@ -1162,6 +1192,8 @@ class RetrieverPriorFn(torch.autograd.Function):
 
 
 def retriever_prior(q, c, scale):
+    if _f32(q):
+        return _F32().retriever_prior(q, c, scale)
     return RetrieverPriorFn.apply(q, c, scale)
 
 

@@ -32,9 +32,15 @@ class Config(object):
     """The architecture flags of megatron/arguments.py that the hot path reads."""
 
     def __init__(self, num_layers=12, hidden_size=768, num_attention_heads=12, ffn_hidden_size=3072, max_position_embeddings=512,
-                 layernorm_epsilon=1e-5, init_method_std=0.02, hidden_dropout=0.0, attention_dropout=0.0):
+                 layernorm_epsilon=1e-5, init_method_std=0.02, hidden_dropout=0.0, attention_dropout=0.0, compute_dtype="bf16"):
+        """compute_dtype: "bf16" (the product: bf16 operands and activations, fp32 accumulation / statistics / masters -- what `--fp16` of the
+        shipped scripts maps to) or "fp32" (VALIDATION ONLY: the reference's arithmetic without --fp16, megatron/training.py:55-56, on the
+        fp32 matrix cores; slow, dense layouts, no dropout -- kernels_f32.py, tests/test_parity_fp32_gpu.py)."""
         if not (0.0 <= hidden_dropout < 1.0 and 0.0 <= attention_dropout < 1.0):
             raise ValueError("dropout probabilities must be in [0, 1)")
+        if compute_dtype not in ("bf16", "fp32"):
+            raise ValueError("compute_dtype must be 'bf16' or 'fp32'")
+        self.compute_dtype = compute_dtype
         self.hidden_dropout, self.attention_dropout = float(hidden_dropout), float(attention_dropout)
         self.num_layers, self.hidden_size, self.num_attention_heads = num_layers, hidden_size, num_attention_heads
         self.ffn_hidden_size, self.max_position_embeddings = ffn_hidden_size, max_position_embeddings
@@ -256,6 +262,7 @@ class Embedding(torch.nn.Module):
         self.position_embeddings = _Table(cfg.max_position_embeddings, cfg.hidden_size, cfg.init_method_std)
         self.tokentype_embeddings = _Table(num_tokentypes, cfg.hidden_size, cfg.init_method_std) if num_tokentypes > 0 else None
         self.embedding_dropout, self._site = cfg.hidden_dropout, K.DROPOUT.new_site()          # language_model.py:289: hidden_dropout
+        self.fp32 = getattr(cfg, "compute_dtype", "bf16") == "fp32"
 
     def forward(self, ids, tokentype_ids=None, seqs=None):
         """[b, s, h] from ids (+ token types) [b, s]; or, with `seqs` (a PackedSeqs built from them), the packed [rows, h]."""
@@ -263,7 +270,7 @@ class Embedding(torch.nn.Module):
         T = self.tokentype_embeddings.weight if with_types else None
         p = self.embedding_dropout if self.training else 0.0
         return K.embedding(ids, tokentype_ids if with_types else None, self.word_embeddings.weight, self.position_embeddings.weight, T, drop_p=p,
-                           seed=K.DROPOUT.seed(self._site) if p else 0, seqs=seqs)
+                           seed=K.DROPOUT.seed(self._site) if p else 0, seqs=seqs, fp32=self.fp32)
 
 
 class TransformerLanguageModel(torch.nn.Module):
@@ -277,7 +284,7 @@ class TransformerLanguageModel(torch.nn.Module):
 
     def packs(self):
         """Whether this stack runs its encoder over packed rows: the switch is on and the fused attention kernels take the head size."""
-        return K.PACKING.enabled and self.encoder.layers[0].self_attention.hn == 64
+        return K.PACKING.enabled and self.encoder.layers[0].self_attention.hn == 64 and not self.embedding.fp32
 
     def encode_packed(self, enc_ids, tokentype_ids=None):
         """(hidden [rows, h], PackedSeqs): the encoder over the real tokens only."""
@@ -298,6 +305,8 @@ class TransformerLanguageModel(torch.nn.Module):
     # ---- incremental decoding (search_strategy.py:185-240 re-decodes the whole prefix for every token) --------------------
     def init_decode_state(self, batch, max_len, device="cuda"):
         """Per-layer self-attention K/V cache [b, Lc, 2, np, hn] (Lc = max_len rounded up to 32: the P V product wants K % 32 == 0)."""
+        if self.embedding.fp32:
+            raise ValueError("incremental decoding is a bf16 path (the fp32 compute mode is for validating forward / loss / backward)")
         lc = (max_len + 31) // 32 * 32
         att = self.decoder.layers[0].self_attention
         return {"len": lc, "kv": [torch.zeros((batch, lc, 2, att.heads, att.hn), dtype=torch.bfloat16, device=device) for _ in self.decoder.layers]}

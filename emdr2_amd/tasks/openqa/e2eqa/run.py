@@ -57,7 +57,7 @@ def model_provider(args=None, bert_tokenizer=None, t5_tokenizer=None, arena=None
     cfg = Config(num_layers=args.num_layers, hidden_size=args.hidden_size, num_attention_heads=args.num_attention_heads,
                  ffn_hidden_size=args.ffn_hidden_size, max_position_embeddings=args.max_position_embeddings,
                  layernorm_epsilon=args.layernorm_epsilon, init_method_std=args.init_method_std, hidden_dropout=args.hidden_dropout,
-                 attention_dropout=args.attention_dropout)
+                 attention_dropout=args.attention_dropout, compute_dtype=getattr(args, "compute_dtype", "bf16"))
     torch.manual_seed(args.seed)
     model = EMDR2Model(retriever, cfg, args.t5_padded_vocab_size, args.bert_padded_vocab_size, args.topk_retrievals, args.seq_length,
                        args.seq_length_ret, cls_id=t5_tokenizer.cls, sep_id=t5_tokenizer.sep, pad_id=t5_tokenizer.pad,
