@@ -71,7 +71,9 @@ def test_task_entry_point_trains_reindexes_checkpoints_evaluates_and_resumes(tmp
     out = capsys.readouterr().out
     assert "MIPS Index Updated" in out and "lm_loss" in out and "Exact Match Score" in out
     stats, total = results["validation"]
-    assert total == 8 and 0.0 <= stats["Exact Match Score"] <= 8.0
+    # (this world's answers are random words no passage contains: nothing here can be learnt, only counted.  That training LEARNS -- retrieval
+    # recall and exact match rise, and only with the retriever loss -- is tests/test_planted_task_gpu.py)
+    assert total == 8 and float(stats["Exact Match Score"]) == int(stats["Exact Match Score"])
     it, release = checkpointing.read_tracker(os.path.join(tmp, "ckpt"))
     assert it == 6 and not release                                      # 24 questions / batch 4, one epoch
     state = torch.load(checkpointing.get_checkpoint_name(os.path.join(tmp, "ckpt"), it), map_location="cpu", weights_only=False)
