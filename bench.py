@@ -53,13 +53,13 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0)
     ap.add_argument("--no-e2e", action="store_true", help="MIPS half only")
-    ap.add_argument("--e2e-steps", type=int, default=5)
+    ap.add_argument("--e2e-steps", type=int, default=10)
     ap.add_argument("--e2e-warmup", type=int, default=1)
-    ap.add_argument("--e2e-timeout", type=float, default=480.0, help="seconds after which rank 0 prints the line without the unfinished e2e objects and exits")
+    ap.add_argument("--e2e-timeout", type=float, default=600.0, help="seconds after which rank 0 prints the line without the unfinished e2e objects and exits")
     ap.add_argument("--no-e2e-k100", action="store_true",
                     help="skip the `e2e_k100` object: BASELINE configs[4] (top-k 100 + continuous re-embedding on a side stream) at its per-rank "
                          "shape -- the N/8-row index shard of an 8-GPU run -- timed with and without the refresher")
-    ap.add_argument("--k100-steps", type=int, default=3)
+    ap.add_argument("--k100-steps", type=int, default=5)
     ap.add_argument("--no-clustered", action="store_true", help="skip the `clustered` object: the same search over a topic-contiguous, anisotropic corpus")
     import bench_e2e
     bench_e2e.add_args(ap)

@@ -14,6 +14,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "gemm_common.h"
+#include "exp_hooks.h"
 #include "ops_timing.h"
 
 #define GNST 3
@@ -111,11 +112,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     const int c_begin = zs * per;
     const int nch = (c_begin + per <= nch_all ? per : (nch_all > c_begin ? nch_all - c_begin : 0));
     if (nch == 0) return;
-#ifdef EMDR2_EXPERIMENTS
-    const int nch_run = p.ablate == 2 ? 0 : nch;
-#else
-    const int nch_run = nch;
-#endif
+    const int nch_run = EXP_GEMM_KLOOP_LEN(p, nch);
     int pf_c = 0, pf_stage = 0;
     auto issue = [&]() {
         const int c = c_begin + (pf_c < nch ? pf_c : nch - 1);      // past the end: harmless re-read, keeps the vmcnt arithmetic fixed
@@ -167,9 +164,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // the two speculative chunks
 
-#ifdef EMDR2_EXPERIMENTS
-    if (p.ablate == 1) { if (acc[0][0][0] == 123.456f) ((float *)p.C)[0] = acc[1][3][5]; return; }
-#endif
+    EXP_GEMM_AFTER_KLOOP(p, acc)
     if (VEC) {
         // ---- vector epilogue: acc -> LDS (fp32, wave-private 32 x 128 half tile, pitch 132) -> 8-wide row segments ----------
         __syncthreads();                                           // every wave is done with the operand ring
@@ -261,9 +256,7 @@ __global__ void __launch_bounds__(WM * WN * 64) gemm_nt_kernel(GemmParams p)
                     uint32_t w[4];
 #pragma unroll
                     for (int j = 0; j < 4; ++j) w[j] = pack2_bf16(v[2 * j], v[2 * j + 1]);
-#ifdef EMDR2_EXPERIMENTS
-                    if (p.ablate != 3 || w[0] == 0x12345678u)
-#endif
+                    EXP_GEMM_STORE_IF(p, w)
                     store_stream((uint16_t *)p.C + o, make_uint4(w[0], w[1], w[2], w[3]));
                 }
             }
@@ -320,13 +313,7 @@ static int launch_gemm_v(const GemmParams &p, int batch, hipStream_t stream)
     }
     GemmParams q = p;
     q.tiles_m = (p.M + BM - 1) / BM; q.tiles_n = (p.N + BN - 1) / BN;
-#ifdef EMDR2_EXPERIMENTS
-    static const int order_env = getenv("EMDR2_GEMM_ORDER") ? atoi(getenv("EMDR2_GEMM_ORDER")) : 1;
-    static const int ablate_env = getenv("EMDR2_GEMM_ABLATE") ? atoi(getenv("EMDR2_GEMM_ABLATE")) : 0;
-    static const int l2_env = getenv("EMDR2_GEMM_L2_KB") ? atoi(getenv("EMDR2_GEMM_L2_KB")) : 2560;
-#else
-    constexpr int order_env = 1, ablate_env = 0, l2_env = 2560;
-#endif
+    EXP_GEMM_TILE_ORDER(order_env, ablate_env, l2_env)
     q.ablate = ablate_env;
     q.order = (order_env >= 1 && q.tiles_n > 1 && q.tiles_m > 8) ? 1 : 0;
     // B panels of BN x K bf16 that fit about half of a 4 MB L2 (the rest holds the A panels in flight and the output lines in transit)
@@ -374,27 +361,14 @@ extern "C" int emdr2_gemm_nt_bf16(const void *A, int64_t lda, const void *B, int
     OpsTimer timer(OPS_GEMM_NT, 2.0 * M * (double)N * K * batch, (hipStream_t)stream);
     if (batch == 1 && split_k == 1 && !out_f32) {
         // large unbatched linears: the persistent 256 x 256 x 64 kernel (gemm8.hip); -4 = shape not covered there
-#ifdef EMDR2_EXPERIMENTS
-        static const int g8_env = getenv("EMDR2_GEMM8") ? atoi(getenv("EMDR2_GEMM8")) : 1;
-        if (g8_env)
-#endif
-        {
+        if (EXP_GEMM_USE_GEMM8()) {
             const int rc = emdr2_gemm8_try(A, lda, B, ldb, C, ldc, M, N, K, alpha, bias, gelu, pre_act, residual, residual_mode, drop_p, seed, (hipStream_t)stream);
             if (rc != -4) return rc;
         }
     }
     if (N <= 128) return launch_gemm<8, 1>(p, batch, (hipStream_t)stream);
     if (M <= 128) return launch_gemm<2, 4>(p, batch, (hipStream_t)stream);
-#ifdef EMDR2_EXPERIMENTS
-    static const int tile_env = getenv("EMDR2_GEMM_TILE") ? atoi(getenv("EMDR2_GEMM_TILE")) : 42;
-    // EMDR2_GEMM_TILE=22: 128 x 256 tiles on 4 waves, two workgroups per CU (one's epilogue overlaps the other's MFMA loop).  Measured
-    // 5-8 % SLOWER than 256 x 256 on the step's linears (1.5x the L2->LDS operand traffic per flop), kept for experiments only.
-    if (tile_env == 22 && split_k == 1) return launch_gemm<2, 2>(p, batch, (hipStream_t)stream);
-    if (tile_env == 21 && split_k == 1) return launch_gemm<2, 1>(p, batch, (hipStream_t)stream);
-    // EMDR2_GEMM_TILE=44: 256 x 256 tile on FOUR waves of 128 x 128 (256 accumulator registers per lane, one wave per SIMD): 8 fragment
-    // reads per 16 MFMAs instead of 6 per 8 -> a third less LDS read traffic per flop
-    if (tile_env == 44 && split_k == 1) return launch_gemm<2, 2, 4>(p, batch, (hipStream_t)stream);
-#endif
+    EXP_GEMM_TILE_VARIANTS(p, batch, split_k, stream)
     // few output tiles (the decoder's 2,048-row batches, decoding): a 256 x 256 tile per workgroup would leave most of the 256 CUs idle and
     // every workgroup with the whole K loop to itself -- 128 x 256 tiles (4 waves) while they still make ~128 workgroups, else 128 x 128
     // (2 waves).  M = 2,048: N = K = 768 26 -> 17 us, K = 3,072 77 -> 46 us, N = 3,072 29 -> 22 us.

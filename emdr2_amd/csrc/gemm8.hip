@@ -28,6 +28,7 @@
 // each row's 256-column tile to (max, sum exp) and picks the gold logit, so the [tokens, vocab] matrix never reaches HBM.
 #include "../../include/emdr2_ops.h"
 #include "gemm_common.h"
+#include "exp_hooks.h"
 #include "ops_timing.h"
 #include <stdlib.h>
 
@@ -272,16 +273,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
         char *stg = smem + G8_STAGING + wave * 4096;            // wave-private: 32 rows x 64 bf16, 8-B slots XOR-swizzled with (row & 15)
         const int prow = elane >> 3, pc16 = elane & 7;           // row-order pass: 8 lanes cover one 128-byte row segment, 8 rows per pass
 
-#ifdef EMDR2_EXPERIMENTS
-        if (p.ablate == 1) {
-#pragma unroll
-            for (int mi = 0; mi < 8; ++mi)
-#pragma unroll
-                for (int ni = 0; ni < 4; ++ni) asm volatile("" ::"v"(acc[mi][ni]));
-            if (wr == 1) { G8_BARRIER(); }
-            continue;
-        }
-#endif
+        EXP_G8_AFTER_KLOOP(p, acc, wr)
         constexpr bool LSE = (EPI & G8_LSE) != 0, HAS_BIAS = (EPI & G8_BIAS) != 0, HAS_RES = (EPI & (G8_RADD | G8_RGELU | G8_RMUL)) != 0;
         constexpr bool PREG = (EPI & G8_PREG) != 0;
         if constexpr (!LSE) {
@@ -389,9 +381,7 @@ __global__ void __launch_bounds__(512) gemm8_kernel(G8Params p)
                                 w[q] = pack2_bf16(x0, x1);
                             }
                         }
-#ifdef EMDR2_EXPERIMENTS
-                        if (p.ablate != 2 || w[0] == 0x12345678u)
-#endif
+                        EXP_G8_STORE_IF(p, w)
                         store_stream((uint16_t *)(outp + (mi * 4 + ps) * pitch8), make_uint4(w[0], w[1], w[2], w[3]));
                     }
                     asm volatile("" ::: "memory");                       // (the next pass's writes queue behind these reads in the same in-order LDS pipe)
@@ -482,17 +472,9 @@ int g8_launch(G8Params &p, hipStream_t stream)
     int ng = (int)(2560ll * 1024 / panel);
     if (ng < 1) ng = 1;
     long long single_kb = 4096;                               // a B matrix up to this size is walked as ONE group (plain n-fastest)
-#ifdef EMDR2_EXPERIMENTS
-    static const int single_env = getenv("EMDR2_G8_SINGLE_KB") ? atoi(getenv("EMDR2_G8_SINGLE_KB")) : 0;
-    if (single_env > 0) single_kb = single_env;
-#endif
+    EXP_G8_HOST_L2(single_kb)
     if (ng > p.tiles_n || 2 * ng < p.tiles_n || (long long)p.N * p.K * 2 <= (single_kb << 10)) ng = p.tiles_n;
-#ifdef EMDR2_EXPERIMENTS
-    static const int ng_env = getenv("EMDR2_G8_NGROUP") ? atoi(getenv("EMDR2_G8_NGROUP")) : 0;
-    if (ng_env > 0) ng = ng_env < p.tiles_n ? ng_env : p.tiles_n;
-    static const int nt_env = getenv("EMDR2_G8_NT") ? atoi(getenv("EMDR2_G8_NT")) : 0;
-    p.nt_a = nt_env;
-#endif
+    EXP_G8_HOST_GROUPS(p, ng)
     const int groups = (p.tiles_n + ng - 1) / ng;
     p.ngroup = (p.tiles_n + groups - 1) / groups;
     auto magic = [](long long d) { return (uint32_t)(((1ull << 32) + (unsigned long long)d - 1) / (unsigned long long)d); };
@@ -501,12 +483,7 @@ int g8_launch(G8Params &p, hipStream_t stream)
     p.mg_full = magic((long long)p.ngroup * p.tiles_m); p.mg_group = p.ngroup > 1 ? magic(p.ngroup) : 0; p.mg_last = last > 1 ? magic(last) : 0;
     // one K-tile takes ~3,200 shader cycles at the sustained rate; 1/8 of that per XCD index, in 1,024-cycle naps: 3200 / 8 / 1024 * 64 = 25
     p.stagger = p.total >= 4 * grid_for(p) ? 25 : 0;             // only when every workgroup has several tiles to amortise the late start
-#ifdef EMDR2_EXPERIMENTS
-    static const int ablate_env = getenv("EMDR2_G8_ABLATE") ? atoi(getenv("EMDR2_G8_ABLATE")) : 0;
-    static const int stagger_env = getenv("EMDR2_G8_STAGGER") ? atoi(getenv("EMDR2_G8_STAGGER")) : -1;
-    p.ablate = ablate_env;
-    if (stagger_env >= 0) p.stagger = stagger_env;
-#endif
+    EXP_G8_HOST_LAUNCH(p)
     const int grid = grid_for(p);
     hipLaunchKernelGGL((gemm8_kernel<EPI>), dim3(grid), dim3(512), LDS, stream, p);
     return hipGetLastError() == hipSuccess ? 0 : -3;

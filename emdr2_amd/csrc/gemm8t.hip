@@ -24,6 +24,7 @@
 //    against ones: four VALU ops per fragment).
 #include "../../include/emdr2_ops.h"
 #include "gemm_common.h"
+#include "exp_hooks.h"
 #include "ops_timing.h"
 #include <stdlib.h>
 
@@ -82,15 +83,7 @@ __global__ void __launch_bounds__(512) gemm8t_kernel(T8Params p)
         offA[h] = (uint32_t)((4 * wave + dr) * lda2 + ca * 2);
         offB[h] = (uint32_t)((4 * wave + dr) * ldb2 + cb * 2);
     }
-#ifdef EMDR2_EXPERIMENTS
-    const int zs_addr = p.ablate == 3 ? 0 : zs;               // 3 = every slice streams slice 0's rows (fresh lines, but shared by all)
-    const int KT_STREAM = p.ablate == 1 ? 1 : KT;             // 1 = the DMA stream re-reads its first K-tile (always L2-hot)
-    const bool T8_DMA_ON = p.ablate != 2;                     // 2 = no DMA at all
-#else
-    const int zs_addr = zs;
-    const int KT_STREAM = KT;
-    constexpr bool T8_DMA_ON = true;
-#endif
+    EXP_T8_STREAM(p, zs, KT, zs_addr, KT_STREAM, T8_DMA_ON)     // product: zs_addr = zs, KT_STREAM = KT, T8_DMA_ON = true
     const char *sA = p.A + (long long)zs_addr * 64 * lda2, *sB = p.B + (long long)zs_addr * 64 * ldb2;
     const long long hopA = (long long)p.slices * 64 * lda2, hopB = (long long)p.slices * 64 * ldb2;
     int s_kt = 0;
@@ -293,10 +286,7 @@ int emdr2_gemm8t_try(const void *A, int64_t lda, const void *B, int64_t ldb, flo
     p.slices = split_k < p.total_kt ? split_k : p.total_kt;
     p.items = p.tiles * p.slices;
     p.ablate = 0;
-#ifdef EMDR2_EXPERIMENTS
-    static const int ablate_env = getenv("EMDR2_T8_ABLATE") ? atoi(getenv("EMDR2_T8_ABLATE")) : 0;
-    p.ablate = ablate_env;
-#endif
+    EXP_T8_HOST(p)
     p.atomic = split_k > 1;                                   // the caller zeroed C exactly when it asked for more than one slice
     constexpr int LDS = T8_RING;
     static bool attr_done = false;

@@ -17,6 +17,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "ops_timing.h"
+#include "exp_hooks.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -207,10 +208,7 @@ extern "C" int emdr2_gemm_tn_bf16(const void *A, int64_t lda, const void *B, int
     if ((I & 7) || (J & 7) || (lda & 7) || (ldb & 7) || ((uintptr_t)A & 15) || ((uintptr_t)B & 15)) return -1;
     OpsTimer timer(OPS_GEMM_TN, 2.0 * I * (double)J * R, (hipStream_t)stream);
     bool general_only = false;
-#ifdef EMDR2_EXPERIMENTS
-    static const bool tn_old = getenv("EMDR2_TN_OLD") && atoi(getenv("EMDR2_TN_OLD"));
-    general_only = tn_old;
-#endif
+    EXP_TN_GENERAL_ONLY(general_only)
     if (!general_only) {
         const int rc = emdr2_gemm8t_try(A, lda, B, ldb, C, ldc, I, J, R, split_k, colsum_a, (hipStream_t)stream);
         if (rc != -4) return rc;

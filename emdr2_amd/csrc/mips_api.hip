@@ -1,6 +1,7 @@
 // emdr2_amd/csrc/mips_api.hip -- C ABI (include/emdr2_mips.h) over the MIPS kernels.
 #include "../../include/emdr2_mips.h"
 #include "mips_kernels.h"
+#include "exp_hooks.h"
 #include <stdlib.h>
 
 namespace {
@@ -30,16 +31,7 @@ inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // Tuning / ablation switches are read from the environment ONLY in -DEMDR2_EXPERIMENTS builds (`make exp`, used by tools/); the production
 // library always runs the defaults, so a stray variable cannot change (or, with the ablations, corrupt) results.
-int env_int(const char *name, int dflt)
-{
-#ifdef EMDR2_EXPERIMENTS
-    const char *v = getenv(name);
-    return (v && *v) ? atoi(v) : dflt;
-#else
-    (void)name;
-    return dflt;
-#endif
-}
+#define env_int(name, dflt) EXP_ENV_INT(name, dflt)           /* the product build: the default, always */
 
 struct Workspace {
     char *q_frag;
@@ -158,9 +150,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         const uint16_t *qp = (const uint16_t *)queries + (size_t)q0 * dim;
         int rc;
         if ((rc = mips_launch_pack_queries(qp, nqp, dim, BN, w.q_tiled, w.qnorm, stream))) return rc;
-#ifdef EMDR2_EXPERIMENTS
-        if (variant == 0 && scan_kernel == 5 && (rc = mips_launch_pack_queries_frag(qp, nqp, dim, w.q_frag, stream))) return rc;
-#endif
+        EXP_MIPS_PACK_QUERIES_FRAG(variant, scan_kernel, qp, nqp, dim, w, stream, rc)
         const int64_t dense_rows = n_rows < seg0 ? n_rows : seg0;
         unsigned *const count8 = w.count + 512, *const prog0 = count8 + 8 * 512;
         // thresholds, counts, flags -- and the sub-list counts and pair-progress counters of the persistent scan launches -- in one launch
@@ -187,11 +177,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
         sp.trace = (unsigned long long *)w.cand + (size_t)511 * CAPQ; // scratch tail of the candidate area (ABL 9 only)
 
         int scan8_launches = 0;
-#ifdef EMDR2_EXPERIMENTS
-        const bool couple = env_int("EMDR2_MIPS_COUPLE", 1) != 0;
-#else
-        const bool couple = true;
-#endif
+        const bool couple = EXP_MIPS_COUPLE();
         int64_t done = 0, seg_end = dense_rows;
         int64_t next_boundary = (int64_t)seg0 * growth;
         int mode = 1;
@@ -210,17 +196,7 @@ static int search_impl(const void *tiled, int64_t n_rows, int dim, int64_t row_b
                 }
                 if (hipEventRecord(g_timing.ev[2 * g_timing.n], stream) != hipSuccess) return EMDR2_E_LAUNCH;
             }
-#ifdef EMDR2_EXPERIMENTS
-            if (mode == 0 && variant == 0 && ablate > 0) rc = mips_launch_scan_ablate(ablate, sp, grid, stream);
-            else if (mode == 0 && variant == 0 && scan_kernel == 5) {
-                ScanParams sq = sp;
-                sq.q_tiled = w.q_frag;
-                rc = mips_launch_scan_q8(ablate == 53 ? 3 : 0, sq, grid, stream);
-            }
-            else if (mode == 0 && scan_kernel == 2) rc = mips_launch_scan_pp(variant, 3, sp, grid, stream);
-            else if (mode == 0 && scan_kernel == 4) rc = mips_launch_scan_pp(variant, seg_end == n_rows && done >= n_rows / 16 ? 4 : 3, sp, grid, stream);
-            else
-#endif
+            EXP_MIPS_SCAN_VARIANT(mode, variant, ablate, scan_kernel, sp, w, grid, seg_end, n_rows, done, stream, rc)
             {
                 rc = -4;
                 if (mode == 0 && variant <= 1 && scan_kernel == 1) {

@@ -21,6 +21,7 @@
 // LDS: 128 KiB operand ring + 32 KiB survivor queue.
 #include "mips_device.h"
 #include "mips_kernels.h"
+#include "exp_hooks.h"
 
 namespace {
 
@@ -106,9 +107,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     for (int qt = 0; qt < 4; ++qt) {
         const int q = hq * 256 + wc * 64 + qt * 16 + ((lane & 3) * 4 + ((lane & 15) >> 2));      // (tile rows are permuted, see the fragment reads)
         tauv[qt] = q < p.n_q ? p.tau[q] : __builtin_inff();
-#ifdef EMDR2_EXPERIMENTS
-        if (p.tune & 128) tauv[qt] = __builtin_inff();        // timing experiment: the filter never fires
-#endif
+        EXP_SCAN8_TAU(p, tauv, qt)
     }
 
     // ---- LDS-DMA addressing.  The operand images in HBM are LDS images already (mips_device.h: 64-byte rows, 16-byte groups XOR-swizzled with
@@ -243,9 +242,7 @@ __global__ void __launch_bounds__(512) mips_scan8_kernel(Scan8Params P)
     floatx4 acc[8][4];                                         // [16-row tile of the wave's 128 rows][16-query tile of its 64 queries]
     const floatx4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
-#ifdef EMDR2_EXPERIMENTS
-    if (hq == 1) for (int i = 0; i < P.s.tune >> 8; ++i) __builtin_amdgcn_s_sleep(32);      // EMDR2_MIPS_TUNE bits 8..: late start of the second half, 2,048 cycles each
-#endif
+    EXP_SCAN8_LATE_START(P, hq)
     // ---- prologue: the first six half-tiles of the stream, then everybody meets once; the second half then drops one barrier behind
     S8_STAGE(0, 0); S8_STAGE(1, 0); S8_STAGE(2, 0); S8_STAGE(3, 0); S8_STAGE(0, 1); S8_STAGE(1, 1);
     asm volatile("s_waitcnt vmcnt(8)" ::: "memory");          // A0, B0 of K-tile 0 have landed (this wave's pieces)
