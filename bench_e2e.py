@@ -63,7 +63,7 @@ def add_args(ap):
                     help="run the encoder stacks over the reference's padded [batch, S] grids instead of the packed real tokens (A/B)")
     ap.add_argument("--reindex-rows-per-step", type=int, default=0,
                     help="BASELINE configs[5]: re-embed this many evidence rows per training step on a side stream into the spare index image "
-                         "(N / (8 ranks * 500-step reload interval) = 5254 is the 8-GPU pace)")
+                         "(N / (8 ranks * 0.9 * 500-step reload interval) = 5838 is the 8-GPU pace with 10 % slack)")
 
 
 def build_index(rows, rank, world):
@@ -404,7 +404,11 @@ def run_k100(args, rank, world, index=None, steps=2, topk=100, reload_interval=5
     shard_rows = (args.rows + ranks - 1) // ranks if index is None else None
     a = copy.copy(args)
     a.micro_batches = getattr(args, "micro_batches_k100", 8)
-    pace = (args.rows + ranks * reload_interval - 1) // (ranks * reload_interval)
+    # rows per step and rank: one pass over the rank's N / ranks rows within 90 % of the reload interval (async_indexer.PACE_MARGIN: the swap
+    # waits for the slowest rank's pass, so the pace leaves slack instead of needing 489 of the 500 steps)
+    from emdr2_amd.tasks.openqa.e2eqa.async_indexer import PACE_MARGIN
+    paced_steps = max(1, int(reload_interval * PACE_MARGIN))
+    pace = (args.rows + ranks * paced_steps - 1) // (ranks * paced_steps)
     out = {}
     if index is None:
         a.rows = shard_rows
@@ -430,7 +434,7 @@ def run_k100(args, rank, world, index=None, steps=2, topk=100, reload_interval=5
     steps_per_pass = (rank_rows + per_step - 1) // per_step
     out.update({
         "workload": "BASELINE configs[4]: EMDR2 step, B=%d/GPU, top-k %d, S_ret %d, S %d, %d-row index shard per rank (N/%d of %d), refresher at "
-                    "N / (%d ranks x %d-step reload interval) = %d rows per step and rank" % (args.batch, topk, args.seq_ret, args.seq, rank_rows, ranks,
+                    "N / (%d ranks x 0.9 x %d-step reload interval) = %d rows per step and rank" % (args.batch, topk, args.seq_ret, args.seq, rank_rows, ranks,
                                                                                              args.rows, ranks, reload_interval, pace),
         "n_gpus": world, "steps": steps, "ms_per_step": w, "steps_per_s": 1e3 / w,
         "inflation_from_refresh": w / wo - 1.0,

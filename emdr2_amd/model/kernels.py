@@ -934,6 +934,9 @@ class AttentionCoreFn(torch.autograd.Function):
                                                      sk, hn, int(causal), scale, float(drop_p), int(seed), m.data_ptr(), l.data_ptr(), _sp()),
                           "attention_fwd")
         else:
+            if sk % 32:
+                raise ValueError("dense attention operands need a key length that is a multiple of 32 (got %d: K x --seq-length; the reference's "
+                                 "sequence lengths 256 / 512 are; packed layouts take any length)" % sk)
             vT = head_transpose(v, b, sk, heads, hn)
             S = torch.empty((b, heads, sq, sk), dtype=BF16, device=dev)
             gemm_nt(q, q.stride(1), k, k.stride(1), S, sk, sq, sk, hn, b, q.stride(0), k.stride(0), heads * sq * sk, heads, q.stride(2),

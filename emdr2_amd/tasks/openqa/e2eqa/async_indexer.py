@@ -22,6 +22,9 @@ import torch
 from emdr2_amd.indexer_emdr2 import IndexBuilder
 
 
+PACE_MARGIN = 0.9        # fraction of the reload interval a pass over the shard is paced for
+
+
 class AsyncIndexBuilder(IndexBuilder):
     def __init__(self, live_context_model, evidence_arena, index, seq_length_ret, cls_id, sep_id, pad_id=0, batch_size=128,
                  log_interval=1000, index_reload_interval=500, batches_per_pump=None, process_group=None):
@@ -37,8 +40,11 @@ class AsyncIndexBuilder(IndexBuilder):
         self.index_reload_interval = index_reload_interval
         lo, hi = index.local_rows()
         n_batches = (hi - lo + batch_size - 1) // batch_size
-        # default pace: finish one pass over the shard within one reload interval
-        self.batches_per_pump = batches_per_pump or max(1, (n_batches + index_reload_interval - 1) // index_reload_interval)
+        # default pace: finish one pass over the shard within 90 % of a reload interval -- the swap happens at the first step boundary at which
+        # EVERY rank's pass is complete (maybe_swap's MIN all-reduce), and ranks do not finish on the same step (the last shard is shorter,
+        # side-stream batches queue behind training kernels): a pace that needs 489 of 500 steps (r05) left 2 % for all of that
+        paced = max(1, int(index_reload_interval * PACE_MARGIN))
+        self.batches_per_pump = batches_per_pump or max(1, (n_batches + paced - 1) // paced)
         self.stream = torch.cuda.Stream()
         self.done_event = None
         self.last_reload_iteration = 0

@@ -240,7 +240,51 @@ def _check_layers(report, tap, heads):
             _check(report, name + " d " + k, p.grad, P[name + "." + k].grad, LAYER_GRAD, P32[name + "." + k].grad)
 
 
-def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, perturb, layerwise, max_admitted=0):
+def _fp32_mode_against_the_fp32_oracle(m, cfg_kw, shapes, inputs, ref32, P32, tol=1e-3):
+    """r06: the SAME weights and batch through the validation-only fp32 compute mode (Config(compute_dtype="fp32"), kernels_f32.py) against
+    the fp32 form of the oracle that the bf16 comparison has just computed: north_star's "logits within 1e-3 fp32" at the BASELINE
+    architecture (12 layers per stack, H 768, full vocabularies).  Every position, padded ones included (dense layouts)."""
+    from emdr2_amd.model import kernels as K
+    from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
+    from emdr2_amd.model.transformer import Config
+    V_t5, V_bert, Kk, S, S_ret, eos = shapes
+    qb, ctx, typ, qext, qone, dec, labels, loss_mask = inputs
+    lm32, tlp32, one32, lm_loss32, r_loss32 = ref32
+    c = _cfg(**cfg_kw)
+    cfg32 = Config(num_layers=c.num_layers, hidden_size=c.hidden_size, num_attention_heads=c.num_attention_heads, ffn_hidden_size=c.ffn_hidden_size,
+                   max_position_embeddings=c.max_position_embeddings, init_method_std=c.init_method_std, compute_dtype="fp32")
+    m32 = EMDR2Model(None, cfg32, V_t5, V_bert, Kk, S, S_ret, cls_id=2, sep_id=3)
+    m32.load_state_dict(m.state_dict())
+    m32.train()
+    q_logits = m32.retriever_embedder(qb.cuda(), None, torch.zeros_like(qb).cuda(), "query")
+    lm, tlp, one = m32.forward_assembled(q_logits, ctx.cuda(), typ.cuda(), qext.cuda(), qone.cuda(), dec.cuda())
+    loss, stats = emdr2_loss(lm, tlp, one, labels.cuda(), loss_mask.cuda(), eos_id=eos)
+    loss.backward()
+    mx = lambda a, b: float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+    rms = lambda a, b: float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+    worst_act = max(mx(lm.detach().cpu(), lm32), mx(one.materialize().cpu(), one32))
+    assert worst_act < tol, worst_act
+    assert float((tlp.detach().cpu() - tlp32).abs().max()) < tol
+    assert abs(float(stats["lm_loss"]) - lm_loss32) < tol * abs(lm_loss32) and abs(float(stats["retriever_loss"]) - r_loss32) < tol * abs(r_loss32)
+    gscale = max(float(v.grad.abs().max()) for v in P32.values() if v.grad is not None)
+    worst, n = 0.0, 0
+    for k, p in m32.named_parameters():
+        g_ref = P32[k].grad
+        if g_ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        if float(g_ref.abs().max()) < 1e-5 * gscale:                     # analytically-zero gradients: fp32 round-off on both sides
+            assert float(p.grad.abs().max()) < 1e-5 * gscale, k
+            continue
+        r = rms(p.grad.cpu(), g_ref)
+        assert r < tol, (k, r)
+        worst, n = max(worst, r), n + 1
+    print("fp32 mode vs fp32 oracle: activations %.2e (max-normalised), worst of %d parameter gradients %.2e (RMS-normalised)" % (worst_act, n, worst))
+    del m32
+    K.WEIGHTS.invalidate()
+
+
+def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, perturb, layerwise, max_admitted=0, fp32_too=False):
     from emdr2_amd.model.emdr2_model import EMDR2Model, emdr2_loss
     rng = np.random.default_rng(seed)
     torch.manual_seed(seed)
@@ -284,6 +328,9 @@ def _emdr2_case(cfg_kw, oracle_cfg, B, Kk, S_ret, S, L, V_t5, V_bert, seed, pert
         assert abs(got - ref) <= max(2e-3 * abs(ref), NOISE_X_ACT * abs(ref - ref32)), (name, got, ref, ref32)
     _check_grads(report, m, P, P32, "", E2E_GRAD)
     _assert_report(report, max_admitted)
+    if fp32_too:
+        _fp32_mode_against_the_fp32_oracle(m, cfg_kw, (V_t5, V_bert, Kk, S, S_ret, eos), (qb, ctx, typ, qext, qone, dec, labels, loss_mask),
+                                           (lm32, tlp32, one32, lm_loss32, r_loss32), P32)
     return 0
 
 
@@ -307,10 +354,11 @@ BASE = dict(layers=12, hidden=768, heads=12, ffn=3072)
 def test_base_size_emdr2_step_vs_bf16_faithful_oracle():
     """The BASELINE architecture itself -- H 768, 12 heads, FFN 3072, 12 + 12 + 12 + 12 layers, the full vocabularies, S_ret 256, S 512,
     L 32 -- at B = 2, K = 4: EMDR2Model forward + EMDR2 loss + backward against the oracle run on the module's own weights
-    (megatron/model/transformer.py:474-563 twelve times per stack, emdr2_model.py:87-214, train_e2eqa.py:72-181)."""
+    (megatron/model/transformer.py:474-563 twelve times per stack, emdr2_model.py:87-214, train_e2eqa.py:72-181).  r06: the same weights and
+    batch also run through the validation-only fp32 compute mode and are held to 1e-3 against the oracle's fp32 form (north_star's fp32 bar)."""
     torch.set_num_threads(min(64, torch.get_num_threads() or 1))
     _emdr2_case(dict(max_pos=512, std=0.02, **BASE), BASE, B=2, Kk=4, S_ret=256, S=512, L=32, V_t5=30720, V_bert=30592, seed=11, perturb=0.01,
-                layerwise=False, max_admitted=340)               # r04: 313 of 692 (gradients through twelve bf16 layers per stack)
+                layerwise=False, max_admitted=340, fp32_too=True)   # r04: 313 of 692 (gradients through twelve bf16 layers per stack)
 
 
 def test_every_layer_of_the_base_size_model_teacher_forced():

@@ -172,3 +172,25 @@ def test_refresher_pass_ready_on_some_ranks_only_at_the_swap_boundary(tmp_path):
     assert all(not sw for r in res for it, _, sw in r["log"] if it < step)               # ... and nobody swapped before everybody was
     assert all(r["same"] and r["refreshes"] == 1 for r in res)
     assert all(torch.equal(r["ids"], res[0]["ids"]) for r in res)
+
+
+def test_task_entry_point_on_eight_ranks(tmp_path):
+    """The training task as the shipped scripts launch it (`python -m torch.distributed.run --nproc-per-node 8 tasks/run.py --task OPENQA ...`,
+    examples/openqa/emdr2_nq.sh:35,106) on EIGHT ranks: the embedding pickle unpickled by the node-first rank only and mapped by all through its
+    flat twin, 8-way row shards (300 rows: 38 per rank, the last one 34), all-gather(queries) + record all-gather + merge per search, bucketed bf16
+    gradient exchange, the refreshers' swap handshake, checkpoint written by rank 0, EM evaluation de-duplicated over the ranks."""
+    from emdr2_amd import checkpointing
+    tmp = str(tmp_path)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tools", "dryrun_task.py"), tmp, "--batch-size", "1", "--question-micro-batches", "2"]
+    import torch
+    torch.cuda.empty_cache()
+    out = subprocess.run(cmd, env=_env(), cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    text = out.stdout.decode()
+    assert out.returncode == 0, text[-3000:]
+    assert all(("rank %d done" % r) in text for r in range(8))
+    assert "MIPS Index Updated" in text and "lm_loss" in text and "Exact Match Score" in text
+    assert os.path.exists(os.path.join(tmp, "emb.flat"))
+    it, release = checkpointing.read_tracker(os.path.join(tmp, "ckpt"))
+    assert it == 3 and not release                                        # 24 questions / (batch 1 x 8 ranks), one epoch
