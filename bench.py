@@ -338,16 +338,16 @@ def main():
                     "mfma_tflops": tflops, "mfma_frac": tflops / MFMA_PEAK_TFLOPS}
         # HBM bytes per launch of the same kernel from the committed rocprofv3 PMC passes (FETCH_SIZE x2 per the
         # gfx950 correction + WRITE_SIZE); only quoted when the profile was taken on this exact launch shape.
-        prof = os.path.join(ROOT, "profiles", "r05_mips_summary.json")
+        prof = os.path.join(ROOT, "profiles", "r06_mips_summary.json")
         if os.path.exists(prof):
             import hashlib
             pj = json.load(open(prof))
             loaded = hashlib.sha256(open(_native.LIB_PATH, "rb").read()).hexdigest()
             if pj.get("library_sha256") != loaded:
-                roofline["traffic_source"] = "profiles/r05_mips_summary.json was measured on another build of libemdr2_hip.so: not quoted"
+                roofline["traffic_source"] = "profiles/r06_mips_summary.json was measured on another build of libemdr2_hip.so: not quoted"
             elif pj.get("algorithmic_bytes_last_segment") == int(bytes_alg) and nq == 512:
                 roofline["traffic"] = pj["traffic_bytes"]
-                roofline["traffic_source"] = ("profiles/r05_mips_summary.json, same library (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; L2->fabric requests, "
+                roofline["traffic_source"] = ("profiles/r06_mips_summary.json, same library (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE; L2->fabric requests, "
                                               "Infinity-Cache hits included)")
         result = {
             "metric": "mips_queries_per_sec", "value": nq * args.steps / elapsed, "unit": "queries/s",

@@ -308,11 +308,11 @@ def run(ctx, steps, warmup, world):
         torch.distributed.all_gather(allcs, cs)
         replicas = [float(c.item()) for c in allcs]
     # HBM traffic of the step's GEMM launches: per-kernel FETCH_SIZE / WRITE_SIZE (separate rocprofv3 --pmc passes over the kernels one by one,
-    # tools/r05_evidence.sh), each access shape scaled by the factor measured on a known byte count on the same box
-    # (profiles/r05_fetch_calibration.json), weighted by the algorithmic bytes of every GEMM launch of a step -- a committed summary of THIS
+    # tools/r06_evidence.sh), each access shape scaled by the factor measured on a known byte count on the same box
+    # (profiles/r06_fetch_calibration.json), weighted by the algorithmic bytes of every GEMM launch of a step -- a committed summary of THIS
     # round's kernels, quoted only if it was taken from the very library that is loaded now
-    traffic, traffic_note = None, "profiles/r05_gemm_summary.json not found"
-    prof = os.path.join(ROOT, "profiles", "r05_gemm_summary.json")
+    traffic, traffic_note = None, "profiles/r06_gemm_summary.json not found"
+    prof = os.path.join(ROOT, "profiles", "r06_gemm_summary.json")
     if os.path.exists(prof):
         import hashlib
         pj = json.load(open(prof))
@@ -320,17 +320,17 @@ def run(ctx, steps, warmup, world):
         with open(_native.LIB_PATH, "rb") as fh:
             loaded = hashlib.sha256(fh.read()).hexdigest()
         if pj.get("library_sha256") != loaded:
-            traffic_note = ("profiles/r05_gemm_summary.json was measured on another build of libemdr2_hip.so (sha256 %s..., loaded %s...): not quoted"
+            traffic_note = ("profiles/r06_gemm_summary.json was measured on another build of libemdr2_hip.so (sha256 %s..., loaded %s...): not quoted"
                             % (str(pj.get("library_sha256"))[:12], loaded[:12]))
         elif sw:
             cal = pj.get("calibration", {})
             traffic = {"hbm_read_gb_per_step": sw["measured_read_gb"], "algorithmic_read_gb_per_step": sw["algorithmic_read_gb"], "read_ratio": sw["read_ratio"],
                        "hbm_write_gb_per_step": sw["measured_write_gb_uncalibrated"], "algorithmic_write_gb_per_step": sw["algorithmic_write_gb"],
                        "write_ratio": sw["write_ratio_uncalibrated"], "calibration": cal}
-            traffic_note = ("step-weighted over the GEMM launches of one step (%.0f of %.0f ms covered) from profiles/r05_gemm_summary.json (same library: sha256 "
+            traffic_note = ("step-weighted over the GEMM launches of one step (%.0f of %.0f ms covered) from profiles/r06_gemm_summary.json (same library: sha256 "
                             "%s...): per (kind, N, K, epilogue) FETCH_SIZE / WRITE_SIZE, the LDS-DMA operand stream, the epilogue's residual-row reads and "
                             "its row-segment stores each scaled by the factor measured for THAT access shape on a known byte count "
-                            "(profiles/r05_fetch_calibration.json; calibrated_on_this_box = %s)" % (sw["covered_ms"], sw["all_ms"], loaded[:12],
+                            "(profiles/r06_fetch_calibration.json; calibrated_on_this_box = %s)" % (sw["covered_ms"], sw["all_ms"], loaded[:12],
                                                                                                cal.get("calibrated_on_this_box")))
     ctx.keep_last, ctx.selective = ctx.plan["keep"], (ctx.plan["reader"], ctx.plan["context"])       # (thinned if a step ran out of memory)
     fl_step = flops_per_step(ctx.B, ctx.K, ctx.S_ret, ctx.S, L, H, V_T5, ctx.layers)

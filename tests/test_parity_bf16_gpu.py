@@ -267,7 +267,7 @@ def _fp32_mode_against_the_fp32_oracle(m, cfg_kw, shapes, inputs, ref32, P32, to
     assert float((tlp.detach().cpu() - tlp32).abs().max()) < tol
     assert abs(float(stats["lm_loss"]) - lm_loss32) < tol * abs(lm_loss32) and abs(float(stats["retriever_loss"]) - r_loss32) < tol * abs(r_loss32)
     gscale = max(float(v.grad.abs().max()) for v in P32.values() if v.grad is not None)
-    worst, n = 0.0, 0
+    worst, n, rows = 0.0, 0, []
     for k, p in m32.named_parameters():
         g_ref = P32[k].grad
         if g_ref is None:
@@ -276,10 +276,18 @@ def _fp32_mode_against_the_fp32_oracle(m, cfg_kw, shapes, inputs, ref32, P32, to
         if float(g_ref.abs().max()) < 1e-5 * gscale:                     # analytically-zero gradients: fp32 round-off on both sides
             assert float(p.grad.abs().max()) < 1e-5 * gscale, k
             continue
-        r = rms(p.grad.cpu(), g_ref)
-        assert r < tol, (k, r)
+        # RMS error over the tensor's own RMS -- but not below 1e-4 of the largest gradient element: the few near-cancelling gradients (the last
+        # context-tower layers' output biases, 3e-5 of the largest: the prior's softmax over K removes almost all of a shift common to every passage
+        # embedding) carry fp32 cancellation noise of 1e-3 of THEMSELVES through twelve layers (measured 1.05e-3; everything else <= 2.7e-4)
+        n_el = float(g_ref.numel()) ** 0.5
+        own = float(g_ref.double().norm()) / n_el
+        r = float((p.grad.cpu().double() - g_ref.double()).norm()) / n_el / max(own, 1e-4 * gscale)
+        rows.append((r, k, float(g_ref.abs().max()) / gscale))
         worst, n = max(worst, r), n + 1
+    rows.sort(reverse=True)
     print("fp32 mode vs fp32 oracle: activations %.2e (max-normalised), worst of %d parameter gradients %.2e (RMS-normalised)" % (worst_act, n, worst))
+    print("worst five (rms error, tensor, its max / the largest gradient):", rows[:5])
+    assert rows[0][0] < tol, rows[:5]
     del m32
     K.WEIGHTS.invalidate()
 
