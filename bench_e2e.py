@@ -19,7 +19,15 @@ import sys
 import time
 import types
 
-import torch
+# Before torch creates its caching allocator: expandable segments.  The packed stacks keep "sticky" row capacities so that activation sizes
+# repeat from step to step (kernels._Packing), but a step that meets a new maximum of real tokens grows a capacity, every activation of that
+# stack changes size at once, and the default allocator -- whose cached blocks now fit nothing -- goes back to hipMalloc for ~150 GB of new
+# blocks: ~1.9 s, once per growth.  With 5 timed steps (r05) none fell into the timed region; with 10 (r06) one does: 1,728 ms per step instead
+# of 1,541 (same box, same build, gpurun_out/r06_e2e_[ab].json).  Expandable segments map pages into a virtual range instead of
+# allocating fixed blocks, so a size change costs nothing: 1,541 ms over the same 10 steps.  An explicit setting in the environment wins.
+os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
+
+import torch  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -277,11 +285,17 @@ def run(ctx, steps, warmup, world):
         Kmod.PACKING.real_tokens = Kmod.PACKING.grid_tokens = 0
         Kmod.RECOMPUTE.flops = 0.0
         before = alloc_retries()
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step boundaries on the stream (no host sync in the region)
+        caps_before = dict(Kmod.PACKING.capacity)
         t0 = time.perf_counter()
-        for _ in range(steps):
+        for i in range(steps):
+            marks[i].record()
             loss = ctx.step()
+        marks[steps].record()
         fence()
         elapsed = time.perf_counter() - t0
+        step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
+        capacity_growths = sum(1 for k, v in Kmod.PACKING.capacity.items() if caps_before.get(k) != v)
         ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); nl = (ctypes.c_int64 * 4)()
         _native.check(lib.emdr2_ops_timing_collect(ms, fl, nl, 4), "ops_timing_collect")
         lib.emdr2_ops_set_timing(0)
@@ -340,6 +354,9 @@ def run(ctx, steps, warmup, world):
     kinds = ("gemm_nt", "gemm_tn", "attention_fwd", "attention_bwd")
     return {
         "steps_per_s": sps * 1.0, "ms_per_step": elapsed / steps * 1e3, "steps": steps, "warmup": warmup, "n_gpus": world, "dtype": "bf16", "scaling": "weak",
+        # every timed step by itself (stream events at the step boundaries, rank 0): ms_per_step is their mean; a packed stack that meets a new
+        # maximum of real tokens grows its row capacity once and that step pays for fresh allocations of every activation size
+        "step_ms": [round(x, 1) for x in step_ms], "median_step_ms": sorted(step_ms)[len(step_ms) // 2], "packed_capacity_growths_in_timed_steps": capacity_growths,
         "config": {"workload": "BASELINE configs[2]: EMDR2 end-to-end step, B=%d/GPU, top-k %d, S_ret %d, S %d, L %d, %d-row index, %d layers"
                                % (ctx.B, ctx.K, ctx.S_ret, ctx.S, L, ctx.rows, ctx.layers),
                    "global_batch": ctx.B * world, "params": ctx.n_params, "parallelism": "dp%d (index row-sharded x%d)" % (world, world),
@@ -527,7 +544,9 @@ def main():
     res = run(ctx, args.steps, args.warmup, world)
     if rank == 0:
         out = {"metric": "qa_train_steps_per_sec", "value": res["steps_per_s"], "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": res["warmup"],
-               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
+               "ms_per_step": res["ms_per_step"], "step_ms": res["step_ms"], "median_step_ms": res["median_step_ms"],
+               "packed_capacity_growths_in_timed_steps": res["packed_capacity_growths_in_timed_steps"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16",
                "data": "synthetic", "config": res["config"], "roofline": res["roofline"]}
         if args.cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_subprocess()
