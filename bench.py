@@ -29,11 +29,8 @@ import os
 import sys
 import time
 
-# before torch creates its caching allocator (bench_e2e.py has the measurement behind this default)
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
+import numpy as np
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

@@ -19,15 +19,7 @@ import sys
 import time
 import types
 
-# Before torch creates its caching allocator: expandable segments.  The packed stacks keep "sticky" row capacities so that activation sizes
-# repeat from step to step (kernels._Packing), but a step that meets a new maximum of real tokens grows a capacity, every activation of that
-# stack changes size at once, and the default allocator -- whose cached blocks now fit nothing -- goes back to hipMalloc for ~150 GB of new
-# blocks: ~1.9 s, once per growth.  With 5 timed steps (r05) none fell into the timed region; with 10 (r06) one does: 1,728 ms per step instead
-# of 1,541 (same box, same build, gpurun_out/r06_e2e_[ab].json).  Expandable segments map pages into a virtual range instead of
-# allocating fixed blocks, so a size change costs nothing: 1,541 ms over the same 10 steps.  An explicit setting in the environment wins.
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-
-import torch  # noqa: E402
+import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -286,7 +278,7 @@ def run(ctx, steps, warmup, world):
         Kmod.RECOMPUTE.flops = 0.0
         before = alloc_retries()
         marks = [torch.cuda.Event(enable_timing=True) for _ in range(steps + 1)]      # per-step boundaries on the stream (no host sync in the region)
-        caps_before = dict(Kmod.PACKING.capacity)
+        growths_before = Kmod.PACKING.growths
         t0 = time.perf_counter()
         for i in range(steps):
             marks[i].record()
@@ -295,14 +287,16 @@ def run(ctx, steps, warmup, world):
         fence()
         elapsed = time.perf_counter() - t0
         step_ms = [marks[i].elapsed_time(marks[i + 1]) for i in range(steps)]
-        capacity_growths = sum(1 for k, v in Kmod.PACKING.capacity.items() if caps_before.get(k) != v)
+        capacity_growths = Kmod.PACKING.growths - growths_before
         ms = (ctypes.c_double * 4)(); fl = (ctypes.c_double * 4)(); nl = (ctypes.c_int64 * 4)()
         _native.check(lib.emdr2_ops_timing_collect(ms, fl, nl, 4), "ops_timing_collect")
         lib.emdr2_ops_set_timing(0)
         # A packed stack that met a new maximum of real tokens grew its (sticky) row capacity inside these steps and, this close to the HBM
         # limit, the caching allocator gave its blocks back to the driver and asked again: seconds, once per new maximum (they stop coming
         # after the first tens of steps).  That is warm-up, not the step: the K steps are timed again, once, and the line says so.
-        retried = alloc_retries() > before
+        # r06: the same holds when the allocator did not have to retry: a capacity that grows changes EVERY activation size of its stack, none
+        # of the cached blocks fit, and the step pays ~1.6 s of fresh hipMallocs (measured: one 3,166 ms step among nine of 1,540)
+        retried = alloc_retries() > before or capacity_growths > 0
         if world > 1:
             t = torch.tensor([int(retried)], device="cuda")
             torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)

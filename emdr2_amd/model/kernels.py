@@ -357,12 +357,13 @@ class _Packing(object):
         self.enabled = True
         self.real_tokens = self.grid_tokens = 0          # running totals over the layouts built so far (bench: tokens_real / tokens_padded)
         self.history = []                                # (n, S, rows) of the most recent layouts (bench: activation budget per stack)
-        # Training loops set `sticky`: the row count of a large stack then never shrinks and grows in 16,384-row steps, per (n, S, fill
-        # octile) -- after a few steps every activation of the stack has the SAME size step after step, which is what lets the caching
+        # Training loops set `sticky`: the row count of a large stack then never shrinks and grows to (new maximum + 1 %) in 2,048-row units, per
+        # (n, S, fill octile) -- after a few steps every activation of the stack has the SAME size step after step, which is what lets the caching
         # allocator reuse its blocks (real-token counts move by a fraction of a percent per step; with free-running sizes two or three size
         # classes of every transient tensor pile up: 58-68 GB "reserved but unallocated" and an out-of-memory after ~10 steps at 230 GB)
         self.sticky = False
         self.capacity = {}
+        self.growths = 0                                 # how often a sticky capacity had to grow (bench: inside the timed steps?)
 
 
 PACKING = _Packing()
@@ -399,11 +400,19 @@ class PackedSeqs(object):
         m = self.ROW_MULTIPLE if self.total < (1 << 16) else (8192 if self.total < (1 << 20) else 16384)
         self.rows = (self.total + m - 1) // m * m
         if PACKING.sticky and self.total >= (1 << 16):
+            # training: a stack's row count is a STICKY capacity -- the same from step to step, so every activation size repeats and the caching
+            # allocator reuses its blocks.  r06: the capacity is the largest token count seen so far + 1 % (the step-to-step spread of a stack's
+            # real tokens is 0.1 - 0.3 %), in 2,048-row units.  (r03 - r05: whole 8,192 / 16,384-row granules plus 16,384 rows on every growth --
+            # sized for the undivided 1.3 M-row stack; on a question group's 0.33 M rows one growth was + 7.5 % rows for the rest of the run:
+            # every step after it 4 % slower, profiles/r06_e2e_capacity_growth.json -- and the growth step itself pays ~1.6 s of fresh hipMallocs
+            # for every activation size, so growths should be rare AND small.)
             key = (n, S, int(8.0 * self.total / (n * S)))
             cap = PACKING.capacity.get(key, 0)
-            if self.rows > cap:
-                cap = self.rows + (16384 if cap else 0)      # a new maximum: one granule of head-room so that the next one rarely follows
+            need = (self.total + 255) // 256 * 256
+            if need > cap:
+                cap = (int(self.total * 1.01) + 2047) // 2048 * 2048
                 PACKING.capacity[key] = cap
+                PACKING.growths += 1
             self.rows = cap
         PACKING.history = PACKING.history[-15:] + [(n, S, self.rows)]
         self.rowmap = torch.empty(self.rows, dtype=torch.int32, device=dev)         # packed row -> dense row (i * S + pos), -1 in the tail

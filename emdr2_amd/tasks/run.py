@@ -4,10 +4,7 @@
 import os
 import sys
 
-# before torch creates its caching allocator: expandable segments (see bench_e2e.py for the measurement behind this default)
-os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "expandable_segments:True")
-
-import torch  # noqa: E402
+import torch
 
 from emdr2_amd import arguments
 from emdr2_amd.global_vars import set_args
