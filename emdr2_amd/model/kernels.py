@@ -357,7 +357,7 @@ class _Packing(object):
         self.enabled = True
         self.real_tokens = self.grid_tokens = 0          # running totals over the layouts built so far (bench: tokens_real / tokens_padded)
         self.history = []                                # (n, S, rows) of the most recent layouts (bench: activation budget per stack)
-        # Training loops set `sticky`: the row count of a large stack then never shrinks and grows to (new maximum + 1 %) in 2,048-row units, per
+        # Training loops set `sticky`: the row count of a large stack then never shrinks and grows to (new maximum + 1 %) in 1,024-row units, per
         # (n, S, fill octile) -- after a few steps every activation of the stack has the SAME size step after step, which is what lets the caching
         # allocator reuse its blocks (real-token counts move by a fraction of a percent per step; with free-running sizes two or three size
         # classes of every transient tensor pile up: 58-68 GB "reserved but unallocated" and an out-of-memory after ~10 steps at 230 GB)
@@ -402,15 +402,16 @@ class PackedSeqs(object):
         if PACKING.sticky and self.total >= (1 << 16):
             # training: a stack's row count is a STICKY capacity -- the same from step to step, so every activation size repeats and the caching
             # allocator reuses its blocks.  r06: the capacity is the largest token count seen so far + 1 % (the step-to-step spread of a stack's
-            # real tokens is 0.1 - 0.3 %), in 2,048-row units.  (r03 - r05: whole 8,192 / 16,384-row granules plus 16,384 rows on every growth --
+            # real tokens is 0.1 - 0.3 %), in 1,024-row units.  (r03 - r05: whole 8,192 / 16,384-row granules plus 16,384 rows on every growth --
             # sized for the undivided 1.3 M-row stack; on a question group's 0.33 M rows one growth was + 7.5 % rows for the rest of the run:
-            # every step after it 4 % slower, profiles/r06_e2e_capacity_growth.json -- and the growth step itself pays ~1.6 s of fresh hipMallocs
-            # for every activation size, so growths should be rare AND small.)
+            # every step after it 3.5 % slower (same box, 10 timed steps: 1,555 ms without a growth, 1,610 after one; this policy 1,564 - 1,572,
+            # profiles/r06_e2e_capacity_policy.txt) -- and the growth step itself pays ~1.6 s of fresh hipMallocs for every activation size, so
+            # growths should be rare AND small.)
             key = (n, S, int(8.0 * self.total / (n * S)))
             cap = PACKING.capacity.get(key, 0)
             need = (self.total + 255) // 256 * 256
             if need > cap:
-                cap = (int(self.total * 1.01) + 2047) // 2048 * 2048
+                cap = (int(self.total * 1.01) + 1023) // 1024 * 1024
                 PACKING.capacity[key] = cap
                 PACKING.growths += 1
             self.rows = cap
