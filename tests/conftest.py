@@ -11,6 +11,8 @@ for p in (ROOT, os.path.join(ROOT, "tests", "golden")):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # torch's own DataLoader pin-memory thread warns once per batch about an argument torch itself passes (11,000 lines per GPU run)
+    config.addinivalue_line("filterwarnings", "ignore:The argument 'device' of Tensor.(pin_memory|is_pinned):DeprecationWarning")
 
 
 def _has_gpu():
